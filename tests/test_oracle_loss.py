@@ -70,8 +70,9 @@ def test_synthetic_vs_reference(golden_loss, name):
     assert abs(loss - golden_loss[f'{name}_loss']) <= RTOL * abs(loss)
     for k, g in enumerate(grads):
         ref = golden_loss[f'{name}_grad{k}']
-        err = np.abs(g - ref).max()
-        assert err <= 1e-4 * np.abs(ref).max(), (k, err, np.abs(ref).max())
+        # see test_fixture_gradient for why max-abs gets 1e-3 of the peak
+        assert np.linalg.norm(g - ref) <= 2e-4 * np.linalg.norm(ref), k
+        assert np.abs(g - ref).max() <= 1e-3 * np.abs(ref).max(), k
 
 
 def test_frame_resolution_is_exact_equality():
