@@ -1,0 +1,249 @@
+"""Loss evaluator with the reference's surface, computed by HIP kernels.
+
+Mirrors /root/reference/utils/loss.py: ``Loss`` (:38-171), ``Losses``
+(:174-214), ``init_losses`` (:217-240), ``interpolate`` (:20-21).  Same call
+signatures, same return structure ``((smooth_k), (photo_k), (border_k))`` of
+0-dim tensors, same assertions on shapes and on frame resolution.
+
+Differences that are deliberate (MI355X-first):
+  * all scales are evaluated by ONE forward launch (+ a 1-workgroup finalize)
+    and ONE backward launch (csrc/loss.hip) instead of ~15 ATen ops per scale;
+  * frames are not gathered (``images[start_indices]``): kernels index the
+    pyramid level through the start/stop index vectors;
+  * ``Losses.fused`` is a training fast path (forward + gradient in one sweep).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .timer import FakeTimer
+
+
+def interpolate(img, shape):
+    """Bilinear resize, align_corners=True (reference utils/loss.py:20-21).
+    img: [..., H, W] float32 device tensor."""
+    _lib.require_cuda(img)
+    img = img.contiguous().float()
+    hin, win = img.shape[-2:]
+    hout, wout = int(shape[0]), int(shape[1])
+    n = img.numel() // (hin * win) if hin * win else 0
+    out = torch.empty(img.shape[:-2] + (hout, wout), dtype=torch.float32,
+                      device=img.device)
+    _lib.check(_lib.lib().dvsof_resize_bilinear_ac(
+        img.data_ptr(), out.data_ptr(), n, hin, win, hout, wout,
+        _lib.stream()), 'dvsof_resize_bilinear_ac')
+    return out
+
+
+def resolve_frames(flow_ts, flow_sample_idx, timestamps, sample_idx):
+    """Start/stop frame of every prediction (reference utils/loss.py:182-206):
+    exact float equality of timestamps AND equal sample id, exactly one hit.
+    Returns int32 device vectors; raises AssertionError like the reference."""
+    same = sample_idx.view(1, -1, 1) == flow_sample_idx.view(1, 1, -1)
+    ts = timestamps.view(1, -1, 1) == flow_ts.T.reshape(2, 1, -1)
+    mask = torch.logical_and(ts, same)                      # [2, D, P]
+    assert bool((mask.sum(1) == 1).all()), \
+        'for each prediction has to be exactly one image in data'
+    idx = mask.to(torch.uint8).argmax(dim=1).to(torch.int32)  # [2, P]
+    return idx[0].contiguous(), idx[1].contiguous()
+
+
+def _scale_array(frames, flows, grads):
+    arr = (_lib.LossScale * len(flows))()
+    for k, f in enumerate(flows):
+        arr[k].frames = frames[k].data_ptr()
+        arr[k].flow = f.data_ptr()
+        arr[k].grad_flow = grads[k].data_ptr() if grads is not None else None
+        arr[k].h, arr[k].w = f.shape[-2], f.shape[-1]
+    return arr
+
+
+def _workspace(arr, K, N, device):
+    nbytes = _lib.lib().dvsof_loss_workspace_bytes(arr, K, N)
+    if nbytes == 0:
+        raise RuntimeError('dvsof_loss_workspace_bytes: invalid scales')
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
+class _LossTerms(torch.autograd.Function):
+    """terms[3,K] = f(flow_0..flow_{K-1}); gradient flows into the flows only
+    (frames are no_grad in the reference, utils/loss.py:209-210)."""
+
+    @staticmethod
+    def forward(ctx, frames, start, stop, *flows):
+        K, N = len(flows), flows[0].shape[0]
+        dev = flows[0].device
+        flows = tuple(f.detach().contiguous().float() for f in flows)
+        arr = _scale_array(frames, flows, None)
+        ws, nbytes = _workspace(arr, K, N, dev)
+        terms = torch.empty(3, K, dtype=torch.float32, device=dev)
+        oob = torch.empty(K * N, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().dvsof_loss_fwd(
+            arr, K, N, start.data_ptr(), stop.data_ptr(), terms.data_ptr(),
+            oob.data_ptr(), ws.data_ptr(), nbytes, _lib.stream()),
+            'dvsof_loss_fwd')
+        ctx.frames, ctx.start, ctx.stop = frames, start, stop
+        ctx.flows, ctx.oob = flows, oob
+        return terms
+
+    @staticmethod
+    def backward(ctx, grad_terms):
+        flows = ctx.flows
+        K, N = len(flows), flows[0].shape[0]
+        grads = tuple(torch.empty_like(f) for f in flows)
+        arr = _scale_array(ctx.frames, flows, grads)
+        seeds = grad_terms.contiguous().float()
+        _lib.check(_lib.lib().dvsof_loss_bwd(
+            arr, K, N, ctx.start.data_ptr(), ctx.stop.data_ptr(),
+            seeds.data_ptr(), ctx.oob.data_ptr(), _lib.stream()),
+            'dvsof_loss_bwd')
+        return (None, None, None) + grads
+
+
+class _FusedLoss(torch.autograd.Function):
+    """loss = sum_t w_t * mean_k term[t,k] * scale with the flow gradients
+    produced in the same sweep (dvsof_loss_fused)."""
+
+    @staticmethod
+    def forward(ctx, frames, start, stop, weights, scale, *flows):
+        K, N = len(flows), flows[0].shape[0]
+        dev = flows[0].device
+        flows = tuple(f.detach().contiguous().float() for f in flows)
+        grads = tuple(torch.empty_like(f) for f in flows)
+        arr = _scale_array(frames, flows, grads)
+        ws, nbytes = _workspace(arr, K, N, dev)
+        terms = torch.empty(3, K, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        oob = torch.empty(K * N, dtype=torch.int32, device=dev)
+        w = (ctypes.c_float * 3)(*[float(x) for x in weights])
+        _lib.check(_lib.lib().dvsof_loss_fused(
+            arr, K, N, start.data_ptr(), stop.data_ptr(), w, float(scale),
+            terms.data_ptr(), loss.data_ptr(), oob.data_ptr(),
+            ws.data_ptr(), nbytes, _lib.stream()), 'dvsof_loss_fused')
+        ctx.grads = grads
+        ctx.mark_non_differentiable(terms)
+        return loss, terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        return (None,) * 5 + tuple(g * g_loss for g in ctx.grads)
+
+
+class Loss:
+    """Single-scale evaluator (reference utils/loss.py:38-171)."""
+
+    def __init__(self, pred_shape, batch_size, device, timers=FakeTimer()):
+        self.N = batch_size
+        self.H, self.W = pred_shape
+        self.device = torch.device(device)
+        self.timers = timers
+
+    def _check(self, prev_images, next_images, flow):
+        N, C, H, W = prev_images.size()
+        assert self.N >= N, 'This object should be used for batch of ' \
+            f'at most {self.N} samples, but {N} samples are given'
+        assert self.H == H, 'This object should be used for images of ' \
+            f'height {self.H}, but image of height {H} are given'
+        assert self.W == W, 'This object should be used for images of ' \
+            f'width {self.W}, but image of width {W} are given'
+        assert tuple(next_images.size()) == (N, C, H, W)
+        assert C == 1, 'frames are single-channel'
+        FN, FC, FH, FW = flow.size()
+        assert FN == N, f'Number of images and flows should be the same ' \
+            f'{N} vs {FN}'
+        assert FC == 2, 'Flow should contain 2 channels (dx and dy)'
+        assert FH == H and FW == W, 'images and flows should have the ' \
+            f'same size {(H, W)} vs {(FH, FW)}'
+
+    def __call__(self, prev_images, next_images, flow):
+        self._check(prev_images, next_images, flow)
+        _lib.require_cuda(prev_images, next_images, flow)
+        N = flow.shape[0]
+        frames = torch.cat([prev_images.reshape(N, self.H, self.W),
+                            next_images.reshape(N, self.H, self.W)]) \
+            .contiguous().float()
+        start = torch.arange(N, dtype=torch.int32, device=flow.device)
+        terms = _LossTerms.apply((frames,), start, start + N, flow)
+        return terms[0, 0], terms[1, 0], terms[2, 0]
+
+
+class Losses:
+    """Multi-scale evaluator (reference utils/loss.py:174-214)."""
+
+    def __init__(self, shapes, batch_size, device, timers=FakeTimer()):
+        self.shapes = [tuple(int(v) for v in s) for s in shapes]
+        self.N = batch_size
+        self.device = torch.device(device)
+        self.timers = timers
+        self.losses = [Loss(s, batch_size, device, timers)
+                       for s in self.shapes]
+
+    def _pyramid(self, flows, images):
+        """CASCADE: level k resamples level k-1 (utils/loss.py:207-210)."""
+        assert len(flows) == len(self.shapes)
+        frames, cur = [], images.detach()
+        cur = cur.reshape(cur.shape[0], cur.shape[-2], cur.shape[-1])
+        for flow, shape in zip(flows, self.shapes):
+            assert tuple(flow.shape[-2:]) == shape, \
+                f'flow of size {tuple(flow.shape[-2:])} given to the ' \
+                f'evaluator of scale {shape}'
+            assert flow.shape[1] == 2, \
+                'Flow should contain 2 channels (dx and dy)'
+            assert flow.shape[0] <= self.N, 'This object should be used ' \
+                f'for batch of at most {self.N} samples'
+            cur = interpolate(cur, shape)
+            frames.append(cur)
+        return tuple(frames)
+
+    def _prepare(self, flows, flow_ts, flow_sample_idx, images, timestamps,
+                 sample_idx, frame_indices):
+        _lib.require_cuda(images, *flows)
+        if frame_indices is None:
+            frame_indices = resolve_frames(flow_ts, flow_sample_idx,
+                                           timestamps, sample_idx)
+        start, stop = frame_indices
+        assert start.numel() == flows[0].shape[0]
+        return self._pyramid(flows, images), start, stop
+
+    def __call__(self, flows, flow_ts, flow_sample_idx, images, timestamps,
+                 sample_idx, frame_indices=None):
+        frames, start, stop = self._prepare(flows, flow_ts, flow_sample_idx,
+                                            images, timestamps, sample_idx,
+                                            frame_indices)
+        terms = _LossTerms.apply(frames, start, stop, *flows)
+        return tuple(tuple(row.unbind(0)) for row in terms.unbind(0))
+
+    def fused(self, flows, flow_ts, flow_sample_idx, images, timestamps,
+              sample_idx, weights=(0.5, 1, 1), loss_scale=1.0,
+              frame_indices=None):
+        """-> (loss, terms[3,K]); same value as combined_loss
+        (reference utils/training.py:12-24) times loss_scale."""
+        frames, start, stop = self._prepare(flows, flow_ts, flow_sample_idx,
+                                            images, timestamps, sample_idx,
+                                            frame_indices)
+        return _FusedLoss.apply(frames, start, stop, tuple(weights),
+                                loss_scale, *flows)
+
+
+def init_losses(shape, batch_size, model, device, sequence_length,
+                timers=FakeTimer()):
+    """Shape discovery by calling the model with ZERO events
+    (reference utils/loss.py:217-240)."""
+    def empty(dtype):
+        return torch.tensor([], dtype=dtype, device=device)
+    events = {'x': empty(torch.long), 'y': empty(torch.long),
+              'timestamp': empty(torch.float32),
+              'polarity': empty(torch.long),
+              'element_index': empty(torch.long),
+              'sample_index': empty(torch.long)}
+    with torch.no_grad():
+        num_timestamps = sequence_length + 1
+        out = model(events,
+                    torch.tensor([0.04 * i for i in range(num_timestamps)],
+                                 dtype=torch.float32, device=device),
+                    torch.tensor([0] * num_timestamps, dtype=torch.long,
+                                 device=device),
+                    shape, raw=True)
+    out_shapes = tuple(tuple(flow.shape[2:]) for flow in out[0])
+    return Losses(out_shapes, batch_size, device, timers=timers)

@@ -1,0 +1,57 @@
+"""Event stream -> count image / voxel grid (HIP, csrc/voxel.hip).
+
+``get_count_image`` mirrors /root/reference/utils/data.py:120-136;
+``voxelize`` is the arithmetic behind ``Model.quantize`` (reference callers
+utils/training.py:59-64, scripts/quantize_preprocessed.py:87-91), specified in
+docs/VOXEL_SPEC.md.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def get_count_image(events, imsize, device='cuda'):
+    """events: [x, y, ...] arrays or tensors; -> uint64 numpy [H,W] like the
+    reference (device tensors in, histogram by integer atomics)."""
+    x, y = [torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v)
+            .to(device=device, dtype=torch.long).contiguous()
+            for v in events[:2]]
+    H, W = int(imsize[0]), int(imsize[1])
+    if x.numel():
+        # np.ravel_multi_index raises for out-of-frame coordinates
+        bad = ((x < 0) | (x >= W) | (y < 0) | (y >= H)).any()
+        if bool(bad):
+            raise ValueError('invalid entry in coordinates array')
+    out = torch.empty(H, W, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().dvsof_count_image(
+        x.data_ptr(), y.data_ptr(), x.numel(), H, W, out.data_ptr(),
+        _lib.stream()), 'dvsof_count_image')
+    return out.cpu().numpy().astype(np.uint32).astype(np.uint64)
+
+
+def voxelize(events, t0, t1, B, C, H, W, debug=False):
+    """events: dict of device tensors in the wire format; t0/t1: float32[B].
+    -> grid float32 [B,C,H,W] (and bin0 int32[n], lin0 int64[n] if debug)."""
+    x = events['x'].contiguous()
+    y = events['y'].contiguous()
+    t = events['timestamp'].contiguous().float()
+    p = events['polarity'].contiguous()
+    s = events['sample_index'].contiguous()
+    _lib.require_cuda(x, y, t, p, s, t0, t1)
+    for v in (x, y, p, s):
+        assert v.dtype == torch.long, 'event columns are int64 on the wire'
+    n = x.numel()
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=t0.device)
+    bin0 = lin0 = None
+    if debug:
+        bin0 = torch.empty(max(n, 1), dtype=torch.int32, device=t0.device)
+        lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=t0.device)
+    _lib.check(_lib.lib().dvsof_voxelize_fwd(
+        x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(), s.data_ptr(),
+        n, t0.contiguous().data_ptr(), t1.contiguous().data_ptr(), B, C, H, W,
+        out.data_ptr(), _lib.ptr(bin0), _lib.ptr(lin0), _lib.stream()),
+        'dvsof_voxelize_fwd')
+    if debug:
+        return out, bin0[:n], lin0[:n]
+    return out

@@ -1,0 +1,139 @@
+/*
+ * dvsof.h -- C ABI of libdvsof_hip.so, the MI355X (gfx950) implementation of
+ * the optical-flow training hot path of e-sha/dvs_of_training_framework.
+ *
+ * Conventions
+ *   - every entry point returns int: 0 = ok, >0 = hipError_t of the failing
+ *     HIP call, <0 = DVSOF_E* argument error.  No exceptions cross the ABI.
+ *   - all pointers are DEVICE pointers unless a parameter is named host_*.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Calls only enqueue work: no allocation, no synchronisation, no
+ *     host<->device copies, so a caller may capture them into a hipGraph.
+ *   - scratch memory is provided by the caller (sizes from *_workspace_bytes);
+ *     the library retains no pointer after a call returns.
+ *   - tensors are dense, row-major, float32 unless stated.  "NCHW"/"NHWC"
+ *     name the memory order.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the reference repository root).
+ */
+#ifndef DVSOF_H
+#define DVSOF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVSOF_VERSION 100 /* 0.1.0 */
+#define DVSOF_MAX_SCALES 8
+
+enum {
+    DVSOF_OK = 0,
+    DVSOF_EINVAL = -1,  /* bad shape / null pointer / unsupported size */
+    DVSOF_ENOSPACE = -2 /* workspace too small */
+};
+
+int dvsof_version(void);
+/* static string for a code returned by any entry point */
+const char *dvsof_error_string(int code);
+
+/* ------------------------------------------------------------------ *
+ * Event stream  ->  images / voxel grids
+ * ------------------------------------------------------------------ */
+
+/*
+ * Per-pixel event count (integer histogram, idx = y*W + x).
+ * Replaces get_count_image, utils/data.py:120-136 (numpy add.at, uint64).
+ * out[H*W] uint32 is zeroed by the call.  Events outside the frame are
+ * ignored (the reference raises; the Python wrapper checks and raises).
+ */
+int dvsof_count_image(const int64_t *x, const int64_t *y, int64_t n_events,
+                      int H, int W, uint32_t *out, void *stream);
+
+/*
+ * Event batch -> polarity-signed, time-bilinear voxel grid out[B,C,H,W]
+ * (NCHW, zeroed by the call), docs/VOXEL_SPEC.md.
+ * Replaces EV_FlowNet Model.quantize / quantization_layer as called at
+ * utils/training.py:59-64 and scripts/quantize_preprocessed.py:87-91; output
+ * contract utils/dataset.py:436-448.  Event columns are the reference's wire
+ * format (utils/dataset.py:961-1020): int64 x,y,polarity,sample_index and
+ * float32 window-relative timestamp.  t0[b], t1[b] are the window of sample b.
+ * n_events may be 0 (utils/loss.py:217-240 probes the model that way).
+ * bin0 (int32[n]) / lin0 (int64[n]) are optional debug outputs: the lower
+ * temporal bin and the linear index of (b,bin0,y,x), -1 for dropped events.
+ */
+int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t,
+                       const int64_t *polarity, const int64_t *sample_index,
+                       int64_t n_events, const float *t0, const float *t1,
+                       int B, int C, int H, int W, float *out, int32_t *bin0,
+                       int64_t *lin0, void *stream);
+
+/* ------------------------------------------------------------------ *
+ * Multi-scale warp / Charbonnier / smoothness / out-of-border loss
+ * ------------------------------------------------------------------ */
+
+/*
+ * Bilinear resize with align_corners=True of n single-channel images.
+ * Replaces utils/loss.py:20-21 (F.interpolate) as used for the CASCADED frame
+ * pyramid at utils/loss.py:207-210.
+ */
+int dvsof_resize_bilinear_ac(const float *src, float *dst, int n, int hin,
+                             int win, int hout, int wout, void *stream);
+
+typedef struct {
+    const float *frames; /* [D,h,w] all frames of the batch at this scale */
+    const float *flow;   /* [N,2,h,w] predicted flow, pixels of this scale */
+    float *grad_flow;    /* [N,2,h,w] written by *_bwd / *_fused, else NULL */
+    int h, w;
+} dvsof_loss_scale_t;
+
+/* bytes of workspace dvsof_loss_* need for these scales (0 on bad input) */
+size_t dvsof_loss_workspace_bytes(const dvsof_loss_scale_t *host_scales,
+                                  int num_scales, int N);
+
+/*
+ * Forward of Losses.__call__ / Loss.__call__, utils/loss.py:121-171,179-214,
+ * for all scales in one launch sequence.
+ *   start_idx/stop_idx  int32[N]: frame index of the first/second image of
+ *                       prediction n (resolved on the host from timestamps,
+ *                       utils/loss.py:182-206)
+ *   terms               float[3*num_scales]: smoothness_k, photometric_k,
+ *                       outborder_k (row order as returned at utils/loss.py:171)
+ *   oob_count           int32[num_scales*N]: out-of-border pixels per sample
+ *                       (utils/loss.py:101), kept for the backward pass
+ */
+int dvsof_loss_fwd(const dvsof_loss_scale_t *host_scales, int num_scales,
+                   int N, const int32_t *start_idx, const int32_t *stop_idx,
+                   float *terms, int32_t *oob_count, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/*
+ * Backward: grad_flow_k = d(sum_t seeds[t,k] * term[t,k]) / d flow_k, i.e.
+ * what loss.backward() (utils/training.py:158) yields through utils/loss.py.
+ * seeds: device float[3*num_scales] (upstream gradients of the 12 scalars).
+ * oob_count: as produced by dvsof_loss_fwd on the same inputs.
+ */
+int dvsof_loss_bwd(const dvsof_loss_scale_t *host_scales, int num_scales,
+                   int N, const int32_t *start_idx, const int32_t *stop_idx,
+                   const float *seeds, const int32_t *oob_count, void *stream);
+
+/*
+ * Training fast path: terms AND the gradient of
+ *   loss = sum_t host_weights[t] * mean_k term[t,k] * loss_scale
+ * (combined_loss, utils/training.py:12-24, with the 1/accumulation_steps of
+ * utils/training.py:156 folded into loss_scale) in one sweep over the inputs.
+ * Also writes the scalar loss to loss_out[0].
+ */
+int dvsof_loss_fused(const dvsof_loss_scale_t *host_scales, int num_scales,
+                     int N, const int32_t *start_idx, const int32_t *stop_idx,
+                     const float *host_weights /*[3]*/, float loss_scale,
+                     float *terms, float *loss_out, int32_t *oob_count,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVSOF_H */
