@@ -1,0 +1,148 @@
+"""Thin Python wrappers over the conv-stack entry points of the C ABI
+(include/dvsof.h: dvsof_conv2d_*, dvsof_flow_head_*, dvsof_act_bwd,
+dvsof_weight_flip_transpose).  Tensors here are raw device buffers with an
+explicit layout tag; predictor.py composes them into the network."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+ACT_NONE, ACT_RELU, ACT_MISH = 0, 1, 2
+NHWC, NCHW = 0, 1
+
+
+class Src(ctypes.Structure):
+    """dvsof_src_t"""
+    _fields_ = [('p', _vp), ('C', _i), ('layout', _i)]
+
+
+class ConvDesc(ctypes.Structure):
+    """dvsof_conv_desc_t"""
+    _fields_ = [('src', Src * 3), ('nsrc', _i), ('B', _i), ('H', _i),
+                ('W', _i), ('upsample', _i), ('ksize', _i), ('stride', _i),
+                ('pad', _i), ('Cout', _i), ('act', _i)]
+
+
+class GradDst(ctypes.Structure):
+    """dvsof_grad_dst_t"""
+    _fields_ = [('p', _vp), ('addend', _vp), ('addend2', _vp),
+                ('actsrc', _vp)]
+
+
+_P = ctypes.POINTER
+_lib.register('dvsof_conv2d_fwd', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp,
+                                       _vp])
+_lib.register('dvsof_conv2d_dgrad', _i, [_P(ConvDesc), _vp, _vp, _P(GradDst),
+                                         _i, _vp])
+_lib.register('dvsof_conv2d_wgrad_workspace_bytes', _sz, [_P(ConvDesc)])
+_lib.register('dvsof_conv2d_wgrad', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp,
+                                         _sz, _vp])
+_lib.register('dvsof_weight_flip_transpose', _i, [_vp, _vp, _i, _i, _i, _vp])
+_lib.register('dvsof_flow_head_fwd', _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                          _vp])
+_lib.register('dvsof_flow_head_bwd_workspace_bytes', _sz, [_i, _i, _i, _i])
+_lib.register('dvsof_flow_head_bwd', _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp,
+                                          _vp, _vp, _i, _i, _i, _i, _vp, _sz,
+                                          _vp])
+_lib.register('dvsof_act_bwd', _i, [_vp, _vp, _i, _vp, _sz, _vp])
+
+
+def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
+              act=ACT_NONE):
+    """srcs: list of (tensor, C, layout)."""
+    d = ConvDesc()
+    d.nsrc = len(srcs)
+    for i, (t, C, layout) in enumerate(srcs):
+        d.src[i].p = t.data_ptr()
+        d.src[i].C = C
+        d.src[i].layout = layout
+    d.B, d.H, d.W = B, H, W
+    d.upsample = 1 if upsample else 0
+    d.ksize, d.stride, d.pad = ksize, stride, pad
+    d.Cout, d.act = Cout, act
+    return d
+
+
+def out_size(desc):
+    up = 2 if desc.upsample else 1
+    ho = (desc.H * up + 2 * desc.pad - desc.ksize) // desc.stride + 1
+    wo = (desc.W * up + 2 * desc.pad - desc.ksize) // desc.stride + 1
+    return ho, wo
+
+
+def _dev(desc_or_tensor):
+    return desc_or_tensor.device
+
+
+def conv_fwd(desc, weight, bias, device, residual=None, want_z=False):
+    """-> y [B,Ho,Wo,Cout] (NHWC buffer), z or None."""
+    ho, wo = out_size(desc)
+    y = torch.empty(desc.B, ho, wo, desc.Cout, dtype=torch.float32,
+                    device=device)
+    z = torch.empty_like(y) if want_z else None
+    _lib.check(_lib.lib().dvsof_conv2d_fwd(
+        ctypes.byref(desc), weight.data_ptr(), _lib.ptr(bias),
+        _lib.ptr(residual), y.data_ptr(), _lib.ptr(z), _lib.stream()),
+        'dvsof_conv2d_fwd')
+    return y, z
+
+
+def flip_transpose(weight, Cout, ksize, Ctot):
+    wt = torch.empty(Ctot * ksize * ksize * Cout, dtype=torch.float32,
+                     device=weight.device)
+    _lib.check(_lib.lib().dvsof_weight_flip_transpose(
+        weight.data_ptr(), wt.data_ptr(), Cout, ksize, Ctot, _lib.stream()),
+        'dvsof_weight_flip_transpose')
+    return wt
+
+
+def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE):
+    """dsts: list of dict(p=, addend=, addend2=, actsrc=) per source."""
+    arr = (GradDst * len(dsts))()
+    for i, d in enumerate(dsts):
+        arr[i].p = d['p'].data_ptr()
+        arr[i].addend = _lib.ptr(d.get('addend'))
+        arr[i].addend2 = _lib.ptr(d.get('addend2'))
+        arr[i].actsrc = _lib.ptr(d.get('actsrc'))
+    _lib.check(_lib.lib().dvsof_conv2d_dgrad(
+        ctypes.byref(desc), weight_t.data_ptr(), gout.data_ptr(), arr,
+        bwd_act, _lib.stream()), 'dvsof_conv2d_dgrad')
+
+
+def conv_wgrad(desc, gout, dweight, dbias):
+    nbytes = _lib.lib().dvsof_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32,
+                     device=gout.device)
+    _lib.check(_lib.lib().dvsof_conv2d_wgrad(
+        ctypes.byref(desc), gout.data_ptr(), dweight.data_ptr(),
+        _lib.ptr(dbias), ws.data_ptr(), ws.numel() * 4, _lib.stream()),
+        'dvsof_conv2d_wgrad')
+
+
+def head_fwd(x, w, bias, B, H, W, C):
+    flow = torch.empty(B, 2, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().dvsof_flow_head_fwd(
+        x.data_ptr(), w.data_ptr(), _lib.ptr(bias), flow.data_ptr(), B, H, W,
+        C, _lib.stream()), 'dvsof_flow_head_fwd')
+    return flow
+
+
+def head_bwd(x, w, gflow, gx_in, actsrc, act, gx, dw, dbias, B, H, W, C):
+    nbytes = _lib.lib().dvsof_flow_head_bwd_workspace_bytes(B, H, W, C)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().dvsof_flow_head_bwd(
+        x.data_ptr(), w.data_ptr(), gflow.data_ptr(), _lib.ptr(gx_in),
+        _lib.ptr(actsrc), act, gx.data_ptr(), dw.data_ptr(),
+        _lib.ptr(dbias), B, H, W, C, ws.data_ptr(), nbytes, _lib.stream()),
+        'dvsof_flow_head_bwd')
+
+
+def act_bwd(dy, actsrc, act, out=None):
+    out = dy if out is None else out
+    _lib.check(_lib.lib().dvsof_act_bwd(
+        dy.data_ptr(), actsrc.data_ptr(), act, out.data_ptr(), dy.numel(),
+        _lib.stream()), 'dvsof_act_bwd')
+    return out

@@ -1,0 +1,420 @@
+// C-ABI entry points of the predictor's convolution stack and the small
+// HBM-bound kernels around it (weight flip-transpose, 1x1 flow head forward /
+// backward fused with the activation backward, elementwise act backward).
+#include "conv_common.h"
+
+
+int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st);
+int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats, hipStream_t st);
+size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias);
+
+namespace {
+
+GSrc make_src(const float *p, int C, int layout, int H, int W)
+{
+    GSrc s;
+    s.p = p;
+    s.C = C;
+    if (layout == DVSOF_NCHW) {
+        s.sb = (long long)C * H * W;
+        s.sy = W;
+        s.sx = 1;
+        s.sc = H * W;
+        s.flat = 1;
+    } else {
+        s.sb = (long long)H * W * C;
+        s.sy = W * C;
+        s.sx = C;
+        s.sc = 1;
+        s.flat = ((C & 3) || C < BK) ? 1 : 0;
+    }
+    return s;
+}
+
+bool desc_ok(const dvsof_conv_desc_t *d, int &Ctot, int &Ho, int &Wo)
+{
+    if (!d || d->nsrc < 1 || d->nsrc > 3 || d->B < 1 || d->H < 1 || d->W < 1) return false;
+    if (d->ksize != 1 && d->ksize != 3 && d->ksize != 5) return false;
+    if (d->stride != 1 && d->stride != 2) return false;
+    if (d->upsample && d->stride != 1) return false;
+    if (d->Cout < 1 || d->pad < 0 || d->pad >= d->ksize) return false;
+    Ctot = 0;
+    for (int i = 0; i < d->nsrc; ++i) {
+        if (!d->src[i].p || d->src[i].C < 1) return false;
+        Ctot += d->src[i].C;
+    }
+    const int up = d->upsample ? 2 : 1;
+    Ho = (d->H * up + 2 * d->pad - d->ksize) / d->stride + 1;
+    Wo = (d->W * up + 2 * d->pad - d->ksize) / d->stride + 1;
+    if (Ho < 1 || Wo < 1) return false;
+    if ((long long)d->B * Ho * Wo > 0x7fffffffLL) return false;
+    if ((long long)d->B * d->H * up * d->W * up > 0x7fffffffLL) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void flip_transpose_kernel(const float *__restrict__ w,
+                                                             float *__restrict__ wt, int Cout,
+                                                             int taps, int Ctot)
+{
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Ctot) ? w[((size_t)co * taps + tap) * Ctot + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Ctot && co < Cout)
+            wt[((size_t)ci * taps + (taps - 1 - tap)) * Cout + co] = tile[tx][r];
+    }
+}
+
+// ---- flow head ------------------------------------------------------------
+// LPP = C/4 lanes share one pixel (one float4 of channels each).
+
+template <int LPP>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ x,
+                                                       const float *__restrict__ w,
+                                                       const float *__restrict__ bias,
+                                                       float *__restrict__ flow, int B, int HW)
+{
+    constexpr int C = LPP * 4, PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, sub = lane % LPP, pw = lane / LPP;
+    const f32x4 w0 = *(const f32x4u *)(w + 4 * sub), w1 = *(const f32x4u *)(w + C + 4 * sub);
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+    const long long total = (long long)B * HW;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long base = wave_id * PPW; base < total; base += nwaves * PPW) {
+        const long long pix = base + pw;
+        float p0 = 0.f, p1 = 0.f;
+        if (pix < total) {
+            const f32x4 v = *(const f32x4u *)(x + pix * C + 4 * sub);
+            p0 = v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
+            p1 = v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
+        }
+#pragma unroll
+        for (int off = LPP / 2; off > 0; off >>= 1) {
+            p0 += __shfl_xor(p0, off, 64);
+            p1 += __shfl_xor(p1, off, 64);
+        }
+        if (sub == 0 && pix < total) {
+            const long long b = pix / HW, r = pix - b * HW;
+            flow[(b * 2) * HW + r] = p0 + b0;
+            flow[(b * 2 + 1) * HW + r] = p1 + b1;
+        }
+    }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void head_bwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ gflow,
+    const float *gx_in, const float *__restrict__ actsrc, int act, float *gx,
+    float *__restrict__ part, int B, int HW)
+{
+    constexpr int C = LPP * 4, PPW = 64 / LPP;
+    __shared__ float red[4][2 * C + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPP, pw = lane / LPP;
+    const f32x4 w0 = *(const f32x4u *)(w + 4 * sub), w1 = *(const f32x4u *)(w + C + 4 * sub);
+    const long long total = (long long)B * HW;
+    const long long wave_id = (long long)blockIdx.x * 4 + wave;
+    const long long nwaves = (long long)gridDim.x * 4;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    float s0 = 0.f, s1 = 0.f;
+    for (long long base = wave_id * PPW; base < total; base += nwaves * PPW) {
+        const long long pix = base + pw;
+        if (pix < total) {
+            const long long b = pix / HW, r = pix - b * HW;
+            const float g0 = gflow[(b * 2) * HW + r], g1 = gflow[(b * 2 + 1) * HW + r];
+            const size_t o = (size_t)pix * C + 4 * sub;
+            const f32x4 v = *(const f32x4u *)(x + o);
+            a0 += g0 * v;
+            a1 += g1 * v;
+            if (sub == 0) {
+                s0 += g0;
+                s1 += g1;
+            }
+            f32x4 g = g0 * w0 + g1 * w1;
+            if (gx_in) g += *(const f32x4u *)(gx_in + o);
+            if (actsrc) {
+                const f32x4 sv = *(const f32x4u *)(actsrc + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[i] *= act_bwd(sv[i], act);
+            }
+            *(f32x4u *)(gx + o) = g;
+        }
+    }
+    // lanes with equal `sub` hold partial sums of the same channels
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a0[i] += __shfl_xor(a0[i], off, 64);
+            a1[i] += __shfl_xor(a1[i], off, 64);
+        }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (pw == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[wave][4 * sub + i] = a0[i];
+            red[wave][C + 4 * sub + i] = a1[i];
+        }
+    }
+    if (lane == 0) {
+        red[wave][2 * C] = s0;
+        red[wave][2 * C + 1] = s1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C + 2; i += 256)
+        part[(size_t)blockIdx.x * (2 * C + 2) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// dw[2*C], dbias[2] from the per-workgroup partials, fixed order
+__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const float *__restrict__ part,
+                                                              int nblocks, int C, float *dw,
+                                                              float *dbias)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C + 2) return;
+    double a = 0;
+    for (int b = 0; b < nblocks; ++b) a += (double)part[(size_t)b * (2 * C + 2) + i];
+    if (i < 2 * C) dw[i] = (float)a;
+    else if (dbias) dbias[i - 2 * C] = (float)a;
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *dy,
+                                                      const float *__restrict__ actsrc, int act,
+                                                      float *dz, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 g = *(const f32x4u *)(dy + i);
+            const f32x4 s = *(const f32x4u *)(actsrc + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] *= act_bwd(s[j], act);
+            *(f32x4u *)(dz + i) = g;
+        } else {
+            for (size_t j = i; j < n; ++j) dz[j] = dy[j] * act_bwd(actsrc[j], act);
+        }
+    }
+}
+
+constexpr int HEAD_BLOCKS = 512;
+
+int head_blocks(long long total, int lpp)
+{
+    const long long per_block = 4LL * (64 / lpp);
+    long long nb = (total + per_block - 1) / per_block;
+    return (int)(nb < HEAD_BLOCKS ? (nb < 1 ? 1 : nb) : HEAD_BLOCKS);
+}
+
+void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParams &P)
+{
+    const int up = d->upsample ? 2 : 1;
+    P.nsrc = d->nsrc;
+    for (int i = 0; i < d->nsrc; ++i)
+        P.src[i] = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+    P.B = d->B;
+    P.Hv = d->H * up;
+    P.Wv = d->W * up;
+    P.up = d->upsample ? UP_NEAREST : UP_NONE;
+    P.Ho = Ho;
+    P.Wo = Wo;
+    P.stride = d->stride;
+    P.pad = d->pad;
+    P.ks = d->ksize;
+    P.Cout = d->Cout;
+    P.Cin_tot = Ctot;
+    P.M = d->B * Ho * Wo;
+    P.klen = 0;
+    P.gout = nullptr;
+    P.dW = nullptr;
+    P.dbias = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const float *bias,
+                     const float *residual, float *y, float *z, void *stream)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo) || !weight || !y) return DVSOF_EINVAL;
+    GConvParams P = {};
+    P.nsrc = d->nsrc;
+    for (int i = 0; i < d->nsrc; ++i)
+        P.src[i] = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+    P.ndst = 1;
+    P.dst[0] = {y, residual, nullptr, nullptr, (long long)Ho * Wo * d->Cout, Wo * d->Cout, d->Cout, 1, d->Cout};
+    P.W = weight;
+    P.bias = bias;
+    P.zout = z;
+    P.B = d->B;
+    const int up = d->upsample ? 2 : 1;
+    P.Hv = d->H * up;
+    P.Wv = d->W * up;
+    P.up = d->upsample ? UP_NEAREST : UP_NONE;
+    P.Ho = Ho;
+    P.Wo = Wo;
+    P.stride = d->stride;
+    P.pad = d->pad;
+    P.ks = d->ksize;
+    P.N = d->Cout;
+    P.Cin_tot = Ctot;
+    P.M = d->B * Ho * Wo;
+    P.quad = 0;
+    P.act = d->act;
+    P.bwd_act = ACT_NONE;
+    return gconv_launch(P, 0, as_stream(stream));
+}
+
+int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const float *gout,
+                       const dvsof_grad_dst_t *dst, int bwd_act, void *stream)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo) || !weight_t || !gout || !dst) return DVSOF_EINVAL;
+    GConvParams P = {};
+    P.nsrc = 1;
+    P.src[0] = make_src(gout, d->Cout, DVSOF_NHWC, Ho, Wo);
+    P.ndst = d->nsrc;
+    for (int i = 0; i < d->nsrc; ++i) {
+        if (!dst[i].p) return DVSOF_EINVAL;
+        const GSrc g = make_src(nullptr, d->src[i].C, d->src[i].layout, d->H, d->W);
+        P.dst[i] = {dst[i].p, dst[i].addend, dst[i].addend2, dst[i].actsrc, g.sb, g.sy, g.sx, g.sc, g.C};
+    }
+    P.W = weight_t;
+    P.bias = nullptr;
+    P.zout = nullptr;
+    P.B = d->B;
+    P.ks = d->ksize;
+    P.stride = 1;
+    P.pad = d->ksize - 1 - d->pad;
+    P.N = Ctot;
+    P.Cin_tot = d->Cout;
+    P.act = ACT_NONE;
+    P.bwd_act = bwd_act;
+    if (d->upsample) {  // rows = upsampled pixels, quad-summed to H x W
+        P.up = UP_NONE;
+        P.Hv = Ho;
+        P.Wv = Wo;
+        P.Ho = 2 * d->H;
+        P.Wo = 2 * d->W;
+        P.quad = 1;
+    } else if (d->stride == 2) {  // zero-inserted gout
+        P.up = UP_ZERO;
+        P.Hv = 2 * Ho;
+        P.Wv = 2 * Wo;
+        P.Ho = d->H;
+        P.Wo = d->W;
+        P.quad = 0;
+    } else {
+        P.up = UP_NONE;
+        P.Hv = Ho;
+        P.Wv = Wo;
+        P.Ho = d->H;
+        P.Wo = d->W;
+        P.quad = 0;
+    }
+    P.M = d->B * P.Ho * P.Wo;
+    return gconv_launch(P, 0, as_stream(stream));
+}
+
+size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
+    WGradParams P;
+    fill_wgrad(d, Ctot, Ho, Wo, P);
+    return wgrad_workspace_floats(P, true) * sizeof(float) + 16;
+}
+
+int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dweight, float *dbias,
+                       void *ws, size_t ws_bytes, void *stream)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo) || !gout || !dweight) return DVSOF_EINVAL;
+    WGradParams P;
+    fill_wgrad(d, Ctot, Ho, Wo, P);
+    P.gout = gout;
+    if (wgrad_workspace_floats(P, dbias != nullptr) > 0 && !ws) return DVSOF_ENOSPACE;
+    return wgrad_launch(P, dweight, dbias, (float *)ws, ws_bytes / sizeof(float), as_stream(stream));
+}
+
+int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize, int Ctot,
+                                void *stream)
+{
+    if (!w || !wt || Cout < 1 || ksize < 1 || Ctot < 1) return DVSOF_EINVAL;
+    const int taps = ksize * ksize;
+    dim3 grid((Ctot + 31) / 32, (Cout + 31) / 32, taps);
+    hipLaunchKernelGGL(flip_transpose_kernel, grid, dim3(256), 0, as_stream(stream), w, wt, Cout,
+                       taps, Ctot);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+#define HEAD_DISPATCH(KERNEL, nb, ...)                                                         \
+    switch (C / 4) {                                                                           \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(nb), dim3(256), 0, st, __VA_ARGS__); break;   \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(nb), dim3(256), 0, st, __VA_ARGS__); break;   \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(nb), dim3(256), 0, st, __VA_ARGS__); break; \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(nb), dim3(256), 0, st, __VA_ARGS__); break; \
+    case 64: hipLaunchKernelGGL((KERNEL<64>), dim3(nb), dim3(256), 0, st, __VA_ARGS__); break; \
+    default: return DVSOF_EINVAL;                                                              \
+    }
+
+static bool head_c_ok(int C) { return C == 16 || C == 32 || C == 64 || C == 128 || C == 256; }
+
+int dvsof_flow_head_fwd(const float *x, const float *w, const float *bias, float *flow, int B,
+                        int H, int W, int C, void *stream)
+{
+    if (!x || !w || !flow || B < 1 || H < 1 || W < 1 || !head_c_ok(C)) return DVSOF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int nb = head_blocks((long long)B * H * W, C / 4);
+    HEAD_DISPATCH(head_fwd_kernel, nb, x, w, bias, flow, B, H * W);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+size_t dvsof_flow_head_bwd_workspace_bytes(int B, int H, int W, int C)
+{
+    if (B < 1 || H < 1 || W < 1 || !head_c_ok(C)) return 0;
+    return (size_t)head_blocks((long long)B * H * W, C / 4) * (2 * C + 2) * sizeof(float);
+}
+
+int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow, const float *gx_in,
+                        const float *actsrc, int act, float *gx, float *dw, float *dbias, int B,
+                        int H, int W, int C, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!x || !w || !gflow || !gx || !dw || !ws || B < 1 || H < 1 || W < 1 || !head_c_ok(C))
+        return DVSOF_EINVAL;
+    if (ws_bytes < dvsof_flow_head_bwd_workspace_bytes(B, H, W, C)) return DVSOF_ENOSPACE;
+    hipStream_t st = as_stream(stream);
+    const int nb = head_blocks((long long)B * H * W, C / 4);
+    float *part = (float *)ws;
+    HEAD_DISPATCH(head_bwd_kernel, nb, x, w, gflow, gx_in, actsrc, act, gx, part, B, H * W);
+    DVSOF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((2 * C + 2 + 255) / 256), dim3(256), 0, st,
+                       (const float *)part, nb, C, dw, dbias);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_act_bwd(const float *dy, const float *actsrc, int act, float *dz, size_t n, void *stream)
+{
+    if (!dy || !actsrc || !dz) return DVSOF_EINVAL;
+    if (n == 0) return DVSOF_OK;
+    size_t nb = (n + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy,
+                       actsrc, act, dz, n);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// Gather-convolution as an implicit GEMM on the f32 matrix cores.
+//
+//   out[m][n] = sum_k A[m][k] * W[n][k]
+//   m = output pixel (b,oy,ox)      n = output channel
+//   k = (tap, input channel) over a VIRTUAL input: the channel concatenation
+//       of up to three tensors, optionally 2x nearest-upsampled or 2x
+//       zero-inserted, never materialised in memory.
+//
+// One kernel serves (see conv.py for the wiring):
+//   * forward of every EV_FlowNet predictor layer (strided encoder convs,
+//     residual convs, decoder convs on upsampled concat[x, skip, flow]) with a
+//     fused bias + residual + ReLU/Mish epilogue;
+//   * data-gradient of all of them, as a convolution of the output gradient
+//     with tap-flipped, transposed weights: stride-2 layers read a
+//     zero-inserted virtual input, upsampled decoder layers use quad-major
+//     rows so that the 2x2 sum back to the low-resolution tensor happens in
+//     registers (the 4 quad members are the 4 consecutive accumulator
+//     registers of one lane), and the epilogue scatters channel ranges to
+//     up to three destinations with optional accumulate and act' multiply.
+// Replaces ATen conv2d / conv_transpose / cat / upsample / activation and their
+// autograd inside the (absent) EV_FlowNet predictor called at
+// utils/training.py:59-64 and differentiated at utils/training.py:158.
+//
+// MFMA-bound (v_mfma_f32_32x32x2_f32: 64 cycles per 32x32x2 block per SIMD).
+// Workgroup = 4 waves; wave tile = (TM*32) x (TN*32); K staged through LDS in
+// 16-wide slices [row][k] (row stride 20 floats: conflict-free ds_read_b128),
+// double buffered with register prefetch, one barrier per slice.  Lane half
+// h = lane>>5 reads k = 8j + 4h .. +3 as one b128 and feeds 4 consecutive
+// MFMAs; A and B use the same k permutation, so the sum is unchanged.
+#include "conv_common.h"
+
+namespace {
+
+struct KIter {
+    int s, tap, c0, coff;
+};
+
+__device__ __forceinline__ void kiter_advance(const GConvParams &P, KIter &it, int taps)
+{
+    const int C = P.src[it.s].C;
+    it.c0 += BK;
+    bool next_src;
+    if (P.src[it.s].flat) {
+        next_src = it.c0 >= taps * C;
+    } else {
+        next_src = false;
+        if (it.c0 >= C) {
+            it.c0 = 0;
+            it.tap += 1;
+            next_src = it.tap >= taps;
+        }
+    }
+    if (next_src) {
+        it.coff += C;
+        it.s += 1;
+        it.tap = 0;
+        it.c0 = 0;
+    }
+}
+
+template <int WROWS, int WCOLS, int TM, int TN>
+__global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, const int nsteps)
+{
+    constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    constexpr int RA = BM / 16 < 4 ? 4 : BM / 16;
+    constexpr int RB = BN / 16 < 4 ? 4 : BN / 16;
+    static_assert(WROWS * WCOLS == CONV_NT / kWave, "4 waves");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+    __shared__ int rowB[BM], rowY[BM], rowX[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int taps = P.ks * P.ks;
+
+    for (int r = tid; r < BM; r += CONV_NT) {
+        const int m = m0 + r;
+        int b = 0, y = -(1 << 20), x = -(1 << 20);
+        if (m < P.M) {
+            int oy, ox;
+            if (!P.quad) {
+                ox = m % P.Wo;
+                const int t = m / P.Wo;
+                oy = t % P.Ho;
+                b = t / P.Ho;
+            } else {
+                const int j = m & 3, q = m >> 2, wq = P.Wo >> 1, hq = P.Ho >> 1;
+                const int t = q / wq;
+                ox = 2 * (q - t * wq) + (j & 1);
+                oy = 2 * (t % hq) + (j >> 1);
+                b = t / hq;
+            }
+            y = oy * P.stride - P.pad;
+            x = ox * P.stride - P.pad;
+        }
+        rowB[r] = b;
+        rowY[r] = y;
+        rowX[r] = x;
+    }
+    __syncthreads();
+
+    float ra[RA], rb[RB];
+    bool ldflat = false;
+
+    auto load_tiles = [&](const KIter &it) {
+        const GSrc &S = P.src[it.s];
+        const size_t wrow = (size_t)taps * P.Cin_tot;
+        ldflat = S.flat != 0;
+        if (!ldflat) {
+            const int ky = it.tap / P.ks, kx = it.tap - ky * P.ks;
+            const int c = it.c0 + 4 * (tid & 3);
+            const bool cok = c < S.C;
+#pragma unroll
+            for (int i = 0; i < (BM + 63) / 64; ++i) {
+                const int r = (tid >> 2) + 64 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (BM >= 64 || r < BM) {
+                    const int Y = rowY[r] + ky, X = rowX[r] + kx;
+                    bool ok = cok & ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+                    if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
+                    if (ok) {
+                        const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
+                        v = *(const f32x4u *)(S.p + (size_t)rowB[r] * S.sb + (size_t)ys * S.sy +
+                                              (size_t)xs * S.sx + c);
+                    }
+                }
+                ra[4 * i + 0] = v[0]; ra[4 * i + 1] = v[1];
+                ra[4 * i + 2] = v[2]; ra[4 * i + 3] = v[3];
+            }
+#pragma unroll
+            for (int i = 0; i < (BN + 63) / 64; ++i) {
+                const int r = (tid >> 2) + 64 * i;
+                const int n = n0 + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((BN >= 64 || r < BN) && cok && n < P.N)
+                    v = *(const f32x4u *)(P.W + (size_t)n * wrow + (size_t)it.tap * P.Cin_tot +
+                                          it.coff + c);
+                rb[4 * i + 0] = v[0]; rb[4 * i + 1] = v[1];
+                rb[4 * i + 2] = v[2]; rb[4 * i + 3] = v[3];
+            }
+        } else {
+            const int f = it.c0 + (tid & 15);
+            const bool fok = f < taps * S.C;
+            const int tap = fok ? f / S.C : 0, c = f - tap * S.C;
+            const int ky = tap / P.ks, kx = tap - ky * P.ks;
+#pragma unroll
+            for (int i = 0; i < BM / 16; ++i) {
+                const int r = (tid >> 4) + 16 * i;
+                const int Y = rowY[r] + ky, X = rowX[r] + kx;
+                bool ok = fok & ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+                if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
+                float v = 0.f;
+                if (ok) {
+                    const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
+                    v = S.p[(size_t)rowB[r] * S.sb + (size_t)ys * S.sy + (size_t)xs * S.sx +
+                            (size_t)c * S.sc];
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 16; ++i) {
+                const int n = n0 + (tid >> 4) + 16 * i;
+                rb[i] = (fok && n < P.N)
+                            ? P.W[(size_t)n * wrow + (size_t)tap * P.Cin_tot + it.coff + c]
+                            : 0.f;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        if (!ldflat) {
+            const int kq = 4 * (tid & 3);
+#pragma unroll
+            for (int i = 0; i < (BM + 63) / 64; ++i) {
+                const int r = (tid >> 2) + 64 * i;
+                if (BM >= 64 || r < BM)
+                    *(f32x4 *)&As[buf][r][kq] =
+                        f32x4{ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]};
+            }
+#pragma unroll
+            for (int i = 0; i < (BN + 63) / 64; ++i) {
+                const int r = (tid >> 2) + 64 * i;
+                if (BN >= 64 || r < BN)
+                    *(f32x4 *)&Bs[buf][r][kq] =
+                        f32x4{rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]};
+            }
+        } else {
+            const int k = tid & 15;
+#pragma unroll
+            for (int i = 0; i < BM / 16; ++i) As[buf][(tid >> 4) + 16 * i][k] = ra[i];
+#pragma unroll
+            for (int i = 0; i < BN / 16; ++i) Bs[buf][(tid >> 4) + 16 * i][k] = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    KIter it = {0, 0, 0, 0};
+    load_tiles(it);
+    store_tiles(0);
+    __syncthreads();
+
+    const int lrow = lane & 31, lk = 4 * (lane >> 5);
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        const bool has_next = step + 1 < nsteps;
+        if (has_next) {
+            kiter_advance(P, it, taps);
+            load_tiles(it);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                a[t] = *(const f32x4 *)&As[cur][(wr * TM + t) * 32 + lrow][8 * j + lk];
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                b[t] = *(const f32x4 *)&Bs[cur][(wc * TN + t) * 32 + lrow][8 * j + lk];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i],
+                                                                           acc[tm][tn], 0, 0, 0);
+        }
+        if (has_next) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    const int sshift = P.stride - 1;  // stride is 1 or 2
+    // ---- epilogue: acc[reg] <-> row (reg&3) + 8*(reg>>2) + 4*(lane>>5), col lane&31
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wc * TN + tn) * 32 + lrow;
+        if (n >= P.N) continue;
+        int d = 0, off = 0;
+        for (int dd = 0; dd + 1 < P.ndst; ++dd)
+            if (n >= off + P.dst[dd].C && d == dd) {
+                off += P.dst[dd].C;
+                d = dd + 1;
+            }
+        const GDst &D = P.dst[d];
+        const int c = n - off;
+        const float bias = P.bias ? P.bias[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int rbase = (wr * TM + tm) * 32 + 4 * (lane >> 5);
+            if (!P.quad) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+                    if (m0 + row >= P.M) continue;
+                    const int oy = (rowY[row] + P.pad) >> sshift, ox = (rowX[row] + P.pad) >> sshift;
+                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)oy * D.sy +
+                                     (size_t)ox * D.sx + (size_t)c * D.sc;
+                    float v = acc[tm][tn][reg] + bias;
+                    if (D.addend) v += D.addend[o];
+                    if (D.addend2) v += D.addend2[o];
+                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
+                    if (P.zout) P.zout[o] = v;
+                    D.p[o] = act_fwd(v, P.act);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rbase + 8 * g;
+                    if (m0 + row >= P.M) continue;
+                    const int y = (rowY[row] + P.pad) >> 1, x = (rowX[row] + P.pad) >> 1;
+                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)y * D.sy +
+                                     (size_t)x * D.sx + (size_t)c * D.sc;
+                    float v = (acc[tm][tn][4 * g] + acc[tm][tn][4 * g + 1]) +
+                              (acc[tm][tn][4 * g + 2] + acc[tm][tn][4 * g + 3]) + bias;
+                    if (D.addend) v += D.addend[o];
+                    if (D.addend2) v += D.addend2[o];
+                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
+                    D.p[o] = v;
+                }
+            }
+        }
+    }
+}
+
+int count_steps(const GConvParams &P)
+{
+    const int taps = P.ks * P.ks;
+    int n = 0;
+    for (int s = 0; s < P.nsrc; ++s)
+        n += P.src[s].flat ? (taps * P.src[s].C + BK - 1) / BK : taps * ((P.src[s].C + BK - 1) / BK);
+    return n;
+}
+
+template <int WROWS, int WCOLS, int TM, int TN>
+int launch(const GConvParams &P, hipStream_t st)
+{
+    constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gconv_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), 0, st, P,
+                       count_steps(P));
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+}  // namespace
+
+// Internal entry (not part of the C ABI): picks the tile shape and launches.
+int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
+{
+    if (P.M <= 0 || P.N <= 0 || P.nsrc < 1 || P.nsrc > 3 || P.ndst < 1 || P.ndst > 3)
+        return DVSOF_EINVAL;
+    if (P.quad && ((P.Ho | P.Wo) & 1)) return DVSOF_EINVAL;
+    if (P.stride != 1 && P.stride != 2) return DVSOF_EINVAL;
+    for (int s = 0; s < P.nsrc; ++s)
+        if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
+    int tile = tile_hint;
+    if (tile <= 0) {
+        // largest tile that still gives every CU work (256 CUs)
+        const long long m = P.M, n = P.N;
+        auto blocks = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
+        if (n <= 32) tile = blocks(256, 32) >= 512 ? 4 : 5;
+        else if (n >= 128 && blocks(128, 128) >= 512) tile = 1;
+        else if (blocks(128, 64) >= 512) tile = 2;
+        else tile = 3;
+    }
+    switch (tile) {
+    case 1: return launch<2, 2, 2, 2>(P, st);  // 128 x 128
+    case 2: return launch<2, 2, 2, 1>(P, st);  // 128 x 64
+    case 3: return launch<2, 2, 1, 1>(P, st);  // 64 x 64
+    case 4: return launch<4, 1, 2, 1>(P, st);  // 256 x 32
+    case 5: return launch<4, 1, 1, 1>(P, st);  // 128 x 32
+    default: return DVSOF_EINVAL;
+    }
+}

@@ -1,0 +1,318 @@
+// Weight gradient of the gather-convolution as an implicit GEMM on the f32
+// matrix cores:
+//   dW[co][tap][ci] = sum_pix gout[pix][co] * Xvirt[pix @ tap][ci]
+//   GEMM rows = co, columns = flattened (tap, ci) of one concat member,
+//   K = output pixels, split over blockIdx.z into slabs that a separate pass
+//   adds in a fixed order (bitwise reproducible, no float atomics).
+// The bias gradient (column sums of gout) is accumulated on the VALU by the
+// workgroups of the first column tile while they stream gout anyway.
+// Replaces the ATen convolution_backward(weight, bias) that
+// utils/training.py:158 triggers inside the (absent) EV_FlowNet predictor.
+//
+// Both operands are K-major in memory (pixel rows, channels contiguous), so
+// LDS holds [k][row] slices written with ds_write_b128 and read one float per
+// lane (consecutive lanes -> consecutive banks); at 64 cycles per MFMA the
+// reads are far off the critical path.
+#include "conv_common.h"
+
+
+namespace {
+
+template <int WROWS, int WCOLS, int TM, int TN>
+__global__ __launch_bounds__(CONV_NT) void wgrad_kernel(const WGradParams P)
+{
+    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    constexpr int LDA = BMc + 4, LDB = BN + 4;
+    constexpr int QA = BMc / 4, RPA = CONV_NT / QA, PA = (BK + RPA - 1) / RPA;
+    constexpr int QB = BN / 4, RPB = CONV_NT / QB, PB = (BK + RPB - 1) / RPB;
+    constexpr int RPF = CONV_NT / BN, PF = BK / RPF;  // flat: one column per thread
+    constexpr int NBREG = PB * 4 > PF ? PB * 4 : PF;
+    static_assert(WROWS * WCOLS == CONV_NT / kWave, "4 waves");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int taps = P.ks * P.ks;
+
+    // which concat member / column range this workgroup owns
+    int s = 0;
+    for (int i = 1; i < P.nsrc; ++i)
+        if ((int)blockIdx.x >= P.tile_begin[i]) s = i;
+    const GSrc &S = P.src[s];
+    int coff = 0;
+    for (int i = 0; i < s; ++i) coff += P.src[i].C;
+    const int f0 = ((int)blockIdx.x - P.tile_begin[s]) * BN;
+    const int fmax = taps * S.C;
+    const int co0 = blockIdx.y * BMc;
+    const int kbeg = blockIdx.z * P.klen;
+    const int kend = min(P.M, kbeg + P.klen);
+    const int nsteps = (kend - kbeg + BK - 1) / BK;
+    const bool flat = S.flat != 0;
+    const bool do_bias = (blockIdx.x == 0) && (P.dbias != nullptr);
+
+    // per-thread constants of the loaders
+    const int qa = tid % QA, pra = tid / QA;
+    const bool a_ok = co0 + 4 * qa < P.Cout;
+    const int colB = flat ? tid % BN : 4 * (tid % QB);
+    const int prb = flat ? tid / BN : tid / QB;
+    const int fB = f0 + colB;
+    const bool b_ok = fB < fmax;
+    const int tapB = b_ok ? fB / S.C : 0, cB = fB - tapB * S.C;
+    const int kyB = tapB / P.ks, kxB = tapB - kyB * P.ks;
+
+    f32x4 rga[PA];
+    float rgb[NBREG];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    auto gather = [&](int pix, bool &ok, size_t &o) {
+        ok = b_ok && pix < kend;
+        o = 0;
+        if (!ok) return;
+        const int ox = pix % P.Wo, t = pix / P.Wo;
+        const int oy = t % P.Ho, b = t / P.Ho;
+        const int Y = oy * P.stride - P.pad + kyB, X = ox * P.stride - P.pad + kxB;
+        ok = ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+        if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
+        const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
+        o = (size_t)b * S.sb + (size_t)ys * S.sy + (size_t)xs * S.sx + (size_t)cB * S.sc;
+    };
+
+    auto load_tiles = [&](int kbase) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int r = pra + RPA * i, pix = kbase + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < BK && a_ok && pix < kend)
+                v = *(const f32x4u *)(P.gout + (size_t)pix * P.Cout + co0 + 4 * qa);
+            rga[i] = v;
+        }
+        if (!flat) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int r = prb + RPB * i;
+                bool ok;
+                size_t o;
+                gather(kbase + r, ok, o);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < BK && ok) v = *(const f32x4u *)(S.p + o);
+                rgb[4 * i] = v[0]; rgb[4 * i + 1] = v[1];
+                rgb[4 * i + 2] = v[2]; rgb[4 * i + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                bool ok;
+                size_t o;
+                gather(kbase + prb + RPF * i, ok, o);
+                rgb[i] = ok ? S.p[o] : 0.f;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int r = pra + RPA * i;
+            if (r < BK) *(f32x4 *)&As[buf][r][4 * qa] = rga[i];
+            if (do_bias) bsum += rga[i];
+        }
+        if (!flat) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int r = prb + RPB * i;
+                if (r < BK)
+                    *(f32x4 *)&Bs[buf][r][colB] =
+                        f32x4{rgb[4 * i], rgb[4 * i + 1], rgb[4 * i + 2], rgb[4 * i + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) Bs[buf][prb + RPF * i][colB] = rgb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    if (nsteps > 0) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        const bool has_next = step + 1 < nsteps;
+        if (has_next) load_tiles(kbeg + (step + 1) * BK);
+#pragma unroll
+        for (int q = 0; q < BK / 2; ++q) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = As[cur][2 * q + lh][(wr * TM + t) * 32 + lrow];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = Bs[cur][2 * q + lh][(wc * TN + t) * 32 + lrow];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (has_next) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    const size_t wsize = (size_t)P.Cout * taps * P.Cin_tot;
+    float *dW = P.dW + (size_t)blockIdx.z * wsize;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int f = f0 + (wc * TN + tn) * 32 + lrow;
+        if (f >= fmax) continue;
+        const int tap = f / S.C, c = f - tap * S.C;
+        const size_t col = (size_t)tap * P.Cin_tot + coff + c;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + (wr * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (co < P.Cout) dW[(size_t)co * taps * P.Cin_tot + col] = acc[tm][tn][reg];
+            }
+    }
+
+    if (do_bias) {  // column sums of gout for this K split (fixed order)
+        float *scr = &As[0][0][0];  // RPA x BMc floats, well inside As
+        __syncthreads();
+        *(f32x4 *)&scr[pra * BMc + 4 * qa] = bsum;
+        __syncthreads();
+        if (tid < BMc && co0 + tid < P.Cout) {
+            float t = 0.f;
+            for (int r = 0; r < RPA; ++r) t += scr[r * BMc + tid];
+            P.dbias[(size_t)blockIdx.z * P.Cout + co0 + tid] = t;
+        }
+    }
+}
+
+// out[i] = sum_z slab[z][i], fixed order
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab,
+                                                          float *__restrict__ out, size_t n, int S)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 a = *(const f32x4u *)(slab + i);
+        for (int z = 1; z < S; ++z) a += *(const f32x4u *)(slab + (size_t)z * n + i);
+        *(f32x4u *)(out + i) = a;
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            float a = slab[j];
+            for (int z = 1; z < S; ++z) a += slab[(size_t)z * n + j];
+            out[j] = a;
+        }
+    }
+}
+
+template <int WROWS, int WCOLS, int TM, int TN>
+int launch(WGradParams &P, int S, hipStream_t st)
+{
+    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    const int taps = P.ks * P.ks;
+    int t = 0;
+    for (int s = 0; s < P.nsrc; ++s) {
+        P.tile_begin[s] = t;
+        t += (taps * P.src[s].C + BN - 1) / BN;
+    }
+    P.tile_begin[P.nsrc] = t;
+    dim3 grid(t, (P.Cout + BMc - 1) / BMc, S);
+    hipLaunchKernelGGL((wgrad_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), 0, st, P);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+void tile_dims(int tile, int &bm, int &bn)
+{
+    switch (tile) {
+    case 1: bm = 128; bn = 128; break;
+    case 2: bm = 128; bn = 64; break;
+    case 3: bm = 64; bn = 64; break;
+    case 4: bm = 64; bn = 128; break;
+    default: bm = 32; bn = 128; break;
+    }
+}
+
+int pick_tile(const WGradParams &P)
+{
+    if (P.Cout <= 32) return 5;
+    if (P.Cout <= 64) return 4;
+    return 1;
+}
+
+}  // namespace
+
+// Number of K splits used for this problem (deterministic in the shape).
+int wgrad_splits(const WGradParams &P0, int *tile_out)
+{
+    const int tile = pick_tile(P0);
+    int bm, bn;
+    tile_dims(tile, bm, bn);
+    const int taps = P0.ks * P0.ks;
+    long long tiles = 0;
+    for (int s = 0; s < P0.nsrc; ++s) tiles += (taps * P0.src[s].C + bn - 1) / bn;
+    tiles *= (P0.Cout + bm - 1) / bm;
+    // aim at >= 1024 workgroups, at least 8 K slices (128 pixels) per split
+    int S = (int)((1024 + tiles - 1) / tiles);
+    const int maxS = (P0.M + 127) / 128;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    if (S > 256) S = 256;
+    if (tile_out) *tile_out = tile;
+    return S;
+}
+
+// Internal entry: dW_ws/dbias_ws hold S slabs when S > 1, results go to dW/dbias.
+int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats, hipStream_t st)
+{
+    for (int s = 0; s < P.nsrc; ++s)
+        if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
+    int tile;
+    const int S = wgrad_splits(P, &tile);
+    const size_t wsize = (size_t)P.Cout * P.ks * P.ks * P.Cin_tot;
+    const size_t need = S > 1 ? (size_t)S * (wsize + (dbias ? P.Cout : 0)) : 0;
+    if (need > ws_floats) return DVSOF_ENOSPACE;
+    P.klen = (((P.M + S - 1) / S) + BK - 1) / BK * BK;
+    P.dW = S > 1 ? ws : dW;
+    P.dbias = dbias ? (S > 1 ? ws + (size_t)S * wsize : dbias) : nullptr;
+    int rc;
+    switch (tile) {
+    case 1: rc = launch<2, 2, 2, 2>(P, S, st); break;
+    case 2: rc = launch<2, 2, 2, 1>(P, S, st); break;
+    case 3: rc = launch<2, 2, 1, 1>(P, S, st); break;
+    case 4: rc = launch<2, 2, 1, 2>(P, S, st); break;
+    default: rc = launch<1, 4, 1, 1>(P, S, st); break;
+    }
+    if (rc) return rc;
+    if (S > 1) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wsize + 1023) / 1024)), dim3(256), 0,
+                           st, (const float *)ws, dW, wsize, S);
+        DVSOF_LAUNCH_CHECK();
+        if (dbias) {
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((P.Cout + 1023) / 1024)),
+                               dim3(256), 0, st, (const float *)(ws + (size_t)S * wsize), dbias,
+                               (size_t)P.Cout, S);
+            DVSOF_LAUNCH_CHECK();
+        }
+    }
+    return DVSOF_OK;
+}
+
+size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias)
+{
+    const int S = wgrad_splits(P, nullptr);
+    if (S <= 1) return 0;
+    return (size_t)S * ((size_t)P.Cout * P.ks * P.ks * P.Cin_tot + (with_bias ? P.Cout : 0));
+}

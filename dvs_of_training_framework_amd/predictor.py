@@ -1,0 +1,273 @@
+"""EV_FlowNet predictor (docs/MODEL_SPEC.md) on the HIP conv stack.
+
+The reference imports ``EV_FlowNet.net.Model`` whose source is an un-vendored
+submodule; what the reference pins is the contract:
+4 flow maps coarse to fine at ``imsize // 2**i`` (DummyNet/net.py:59-66,
+tests/training/test_training.py:45-46), attribute ``predictor`` with
+state-dict names ``predictor.enc.N.conv.*`` (train_flownet.py:50-54,79-85).
+The architecture is the canonical EV-FlowNet (Zhu et al., RSS 2018):
+
+  enc.i   3x3 stride-2 conv + act,  C -> 64 -> 128 -> 256 -> 512
+  res.i   x + conv2(act(conv1(x))), then act          (2 blocks at 512)
+  dec.i   3x3 conv + act on the 2x nearest-upsampled concat[x, skip, flow]
+          -> 256, 128, 64, 32;  dec.i.flow = 1x1 conv -> 2 (linear head)
+
+Forward and backward are ONE autograd node with an explicit schedule: the
+backward pass is ~45 launches of the gather-conv / wgrad / head kernels with
+the gradient sums and activation derivatives folded into kernel epilogues
+(no autograd graph, no cat/upsample tensors, no elementwise passes).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import conv as C
+
+ENC_CH = (64, 128, 256, 512)
+DEC_CH = (256, 128, 64, 32)
+NUM_RES = 2
+
+
+def activation_id(activation):
+    """nn.ReLU -> ACT_RELU, Mish-like module -> ACT_MISH
+    (reference: utils/options.py:341-347 passes nn.ReLU() or Mish())."""
+    if activation is None or isinstance(activation, nn.ReLU):
+        return C.ACT_RELU
+    if isinstance(activation, nn.Identity):
+        return C.ACT_NONE
+    if type(activation).__name__.lower() == 'mish':
+        return C.ACT_MISH
+    raise ValueError(f'unsupported activation {activation!r}: the HIP conv '
+                     'stack fuses ReLU or Mish')
+
+
+class ConvParams(nn.Module):
+    """weight [Cout,Cin,k,k] stored channels_last = physical [Cout][k][k][Cin]
+    (the K-contiguous layout the MFMA kernels stream), bias [Cout]."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        w = torch.empty(cout, cin, k, k).contiguous(
+            memory_format=torch.channels_last)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.empty(cout))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # nn.Conv2d's default init
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(self.cin * self.k * self.k)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _Named(nn.Module):
+    def __init__(self, **mods):
+        super().__init__()
+        for k, v in mods.items():
+            self.add_module(k, v)
+
+
+def _phys(w):
+    """Physical [Cout][k][k][Cin] buffer of a channels_last OIHW weight."""
+    assert w.permute(0, 2, 3, 1).is_contiguous(), \
+        'conv weights must stay in channels_last memory format'
+    return w
+
+
+class _PredictorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, act, want_grad, *params):
+        # params: enc(w,b)x4, res(w1,b1,w2,b2)x2, dec(w,b,fw,fb)x4
+        dev = x0.device
+        B, Cin, H, W = x0.shape
+        mish = act == C.ACT_MISH
+        p = list(params)
+        enc = [(p[2 * i], p[2 * i + 1]) for i in range(4)]
+        o = 8
+        res = [(p[o + 4 * i], p[o + 4 * i + 1], p[o + 4 * i + 2],
+                p[o + 4 * i + 3]) for i in range(NUM_RES)]
+        o += 4 * NUM_RES
+        dec = [(p[o + 4 * i], p[o + 4 * i + 1], p[o + 4 * i + 2],
+                p[o + 4 * i + 3]) for i in range(4)]
+        L = []          # per conv layer: dict(desc, y, z, srcs)
+
+        def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
+                residual=None):
+            d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act)
+            y, z = C.conv_fwd(d, _phys(wgt), bias, dev, residual, mish)
+            L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt))
+            return y
+
+        # encoder
+        e, h, w = [], H, W
+        cur, ccur, lay = x0, Cin, C.NCHW
+        for i in range(4):
+            cur = run([(cur, ccur, lay)], h, w, ENC_CH[i], *enc[i], stride=2)
+            h, w, ccur, lay = h // 2, w // 2, ENC_CH[i], C.NHWC
+            e.append(cur)
+        # residual blocks
+        r = e[3]
+        for i in range(NUM_RES):
+            t = run([(r, 512, C.NHWC)], h, w, 512, res[i][0], res[i][1])
+            r = run([(t, 512, C.NHWC)], h, w, 512, res[i][2], res[i][3],
+                    residual=r)
+        # decoder
+        flows, x, cx, f = [], r, 512, None
+        for i in range(4):
+            srcs = [(x, cx, C.NHWC), (e[3 - i], ENC_CH[3 - i], C.NHWC)]
+            if f is not None:
+                srcs.append((f, 2, C.NCHW))
+            x = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True)
+            h, w, cx = 2 * h, 2 * w, DEC_CH[i]
+            f = C.head_fwd(x, dec[i][2], dec[i][3], B, h, w, cx)
+            flows.append(f)
+        if want_grad:
+            ctx.L, ctx.act, ctx.dims = L, act, (B, Cin, H, W)
+            ctx.params = params
+            ctx.flows = flows
+        return tuple(flows)
+
+    @staticmethod
+    def backward(ctx, *gflows):
+        L, act, (B, Cin, H, W) = ctx.L, ctx.act, ctx.dims
+        params = ctx.params
+        dev = gflows[0].device
+        mish = act == C.ACT_MISH
+        grads = [torch.empty_like(q) for q in params]
+        gflows = [g.contiguous() for g in gflows]
+
+        def asrc(layer):        # what act' is evaluated on
+            return layer['z'] if mish else layer['y']
+
+        def wt(layer):
+            d = layer['desc']
+            ctot = sum(s[1] for s in layer['srcs'])
+            return C.flip_transpose(_phys(layer['w']), d.Cout, d.ksize, ctot)
+
+        def new(t):
+            return torch.empty_like(t)
+
+        enc_l, res_l, dec_l = L[0:4], L[4:4 + 2 * NUM_RES], L[4 + 2 * NUM_RES:]
+        po_res, po_dec = 8, 8 + 4 * NUM_RES
+
+        # ---- decoder, fine to coarse
+        g_x = None          # gradient w.r.t. dec[i].y from the finer stage
+        g_f = gflows[3]     # total gradient of the flow of this stage
+        g_skip = [None] * 4  # gradient into e[k] from the decoder
+        g_r = None
+        for i in (3, 2, 1, 0):
+            lay = dec_l[i]
+            d = lay['desc']
+            h, w = C.out_size(d)
+            y = lay['y']
+            gz = new(y)
+            pw, pb, pfw, pfb = (po_dec + 4 * i + j for j in range(4))
+            C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
+                       grads[pfw], grads[pfb], B, h, w, d.Cout)
+            C.conv_wgrad(d, gz, grads[pw], grads[pb])
+            srcs = lay['srcs']
+            g_in = new(srcs[0][0])
+            g_e = new(srcs[1][0])
+            dsts = [dict(p=g_in), dict(p=g_e)]
+            if i == 0:
+                # x = r (last residual output): single consumer -> its dz
+                dsts[0]['actsrc'] = asrc(res_l[-1])
+            if len(srcs) == 3:
+                g_fprev = new(srcs[2][0])
+                dsts.append(dict(p=g_fprev, addend=gflows[i - 1]))
+            C.conv_dgrad(d, wt(lay), gz, dsts, act)
+            g_skip[3 - i] = g_e
+            if i > 0:
+                g_x, g_f = g_in, g_fprev
+            else:
+                g_r = g_in
+        # ---- residual blocks (g_r is already d/d pre-activation)
+        gs = g_r
+        for i in reversed(range(NUM_RES)):
+            l1, l2 = res_l[2 * i], res_l[2 * i + 1]
+            pw1, pb1, pw2, pb2 = (po_res + 4 * i + j for j in range(4))
+            C.conv_wgrad(l2['desc'], gs, grads[pw2], grads[pb2])
+            g_t = new(l1['y'])
+            C.conv_dgrad(l2['desc'], wt(l2), gs,
+                         [dict(p=g_t, actsrc=asrc(l1))], act)
+            C.conv_wgrad(l1['desc'], g_t, grads[pw1], grads[pb1])
+            below = res_l[2 * i - 1] if i > 0 else enc_l[3]
+            g_prev = new(below['y'])
+            dst = dict(p=g_prev, addend=gs, actsrc=asrc(below))
+            if i == 0:
+                dst['addend2'] = g_skip[3]      # dec.0's skip into e4
+            C.conv_dgrad(l1['desc'], wt(l1), g_t, [dst], act)
+            gs = g_prev
+        # ---- encoder
+        gz = gs
+        for i in (3, 2, 1, 0):
+            lay = enc_l[i]
+            C.conv_wgrad(lay['desc'], gz, grads[2 * i], grads[2 * i + 1])
+            if i == 0:
+                break
+            below = enc_l[i - 1]
+            g_prev = new(below['y'])
+            C.conv_dgrad(lay['desc'], wt(lay), gz,
+                         [dict(p=g_prev, addend=g_skip[i - 1],
+                               actsrc=asrc(below))], act)
+            gz = g_prev
+        ctx.L = None
+        return (None, None, None) + tuple(grads)
+
+
+class Predictor(nn.Module):
+    def __init__(self, in_channels, activation=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.act = activation_id(activation)
+        chans = (in_channels,) + ENC_CH
+        self.enc = nn.ModuleList(
+            _Named(conv=ConvParams(chans[i], chans[i + 1], 3))
+            for i in range(4))
+        self.res = nn.ModuleList(
+            _Named(conv1=ConvParams(512, 512, 3), conv2=ConvParams(512, 512, 3))
+            for _ in range(NUM_RES))
+        dec_in = (512 + 512, 256 + 256 + 2, 128 + 128 + 2, 64 + 64 + 2)
+        self.dec = nn.ModuleList(
+            _Named(conv=ConvParams(dec_in[i], DEC_CH[i], 3),
+                   flow=ConvParams(DEC_CH[i], 2, 1))
+            for i in range(4))
+
+    def param_list(self):
+        out = []
+        for m in self.enc:
+            out += [m.conv.weight, m.conv.bias]
+        for m in self.res:
+            out += [m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias]
+        for m in self.dec:
+            out += [m.conv.weight, m.conv.bias, m.flow.weight, m.flow.bias]
+        return out
+
+    def forward(self, voxels):
+        """voxels: float32 [B,C,H,W] (NCHW dense), H and W multiples of 16.
+        -> tuple of 4 flows [B,2,H/8..H,W/8..W] coarse to fine."""
+        B, Cin, H, W = voxels.shape
+        assert Cin == self.in_channels
+        assert H % 16 == 0 and W % 16 == 0, \
+            'the predictor needs H and W divisible by 16'
+        params = self.param_list()
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad
+                                                    for p in params)
+        return _PredictorFn.apply(voxels.contiguous(), self.act, want_grad,
+                                  *params)
+
+    def flops_per_sample(self, H, W):
+        """Algorithmic forward FLOPs (2*MACs), SURVEY.md section 8d formula."""
+        total, h, w, c = 0, H, W, self.in_channels
+        for co in ENC_CH:
+            h, w = h // 2, w // 2
+            total += 2 * h * w * co * c * 9
+            c = co
+        total += 2 * NUM_RES * 2 * h * w * 512 * 512 * 9
+        cin = (1024, 514, 258, 130)
+        for i, co in enumerate(DEC_CH):
+            h, w = 2 * h, 2 * w
+            total += 2 * h * w * co * cin[i] * 9 + 2 * h * w * 2 * co
+        return total

@@ -133,6 +133,102 @@ int dvsof_loss_fused(const dvsof_loss_scale_t *host_scales, int num_scales,
                      float *terms, float *loss_out, int32_t *oob_count,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+
+/* ------------------------------------------------------------------ *
+ * EV_FlowNet predictor: convolution stack on the f32 matrix cores
+ * (docs/MODEL_SPEC.md).  Replaces the ATen conv2d / upsample / cat /
+ * activation ops and their autograd inside EV_FlowNet.net.Model.predictor as
+ * called at utils/training.py:59-64 and differentiated at
+ * utils/training.py:158 (source absent upstream; contract from
+ * DummyNet/net.py:59-80 and tests/training/test_training.py:45-46).
+ * ------------------------------------------------------------------ */
+
+enum { DVSOF_ACT_NONE = 0, DVSOF_ACT_RELU = 1, DVSOF_ACT_MISH = 2 };
+enum { DVSOF_NHWC = 0, DVSOF_NCHW = 1 };
+
+typedef struct {
+    const float *p; /* dense tensor [B,H,W,C] (NHWC) or [B,C,H,W] (NCHW) */
+    int C;
+    int layout; /* DVSOF_NHWC | DVSOF_NCHW */
+} dvsof_src_t;
+
+/*
+ * One conv layer y = act(conv(up(cat(src...)), W) + bias [+ residual]):
+ * the input is the channel concatenation of nsrc tensors of spatial size
+ * H x W, optionally 2x nearest-upsampled first; ksize x ksize taps, zero
+ * padding `pad`, stride 1 or 2.  Output is NHWC [B,Ho,Wo,Cout] with
+ * Ho = (H*(1+upsample) + 2*pad - ksize)/stride + 1.
+ * Weights are [Cout][ksize][ksize][Ctot] (channels contiguous, Ctot = sum C).
+ */
+typedef struct {
+    dvsof_src_t src[3];
+    int nsrc;
+    int B, H, W;
+    int upsample; /* 0 | 1 */
+    int ksize, stride, pad;
+    int Cout;
+    int act; /* DVSOF_ACT_* */
+} dvsof_conv_desc_t;
+
+/* y (and z = pre-activation, optional, for Mish backward) are NHWC. */
+int dvsof_conv2d_fwd(const dvsof_conv_desc_t *desc, const float *weight,
+                     const float *bias, const float *residual, float *y,
+                     float *z, void *stream);
+
+typedef struct {
+    float *p;            /* gradient w.r.t. desc->src[i], same layout/shape */
+    const float *addend; /* optional: p = result + addend (may alias p) */
+    const float *addend2; /* optional second addend */
+    const float *actsrc; /* optional: p *= act'(actsrc), the producer's y
+                            (ReLU) or z (Mish): yields its dz directly */
+} dvsof_grad_dst_t;
+
+/*
+ * Data gradient: for every source i, dst[i].p = d loss / d src[i] given
+ * gout = d loss / d (pre-activation output) [B,Ho,Wo,Cout] NHWC.
+ * weight_t is the tap-flipped transpose [Ctot][ksize][ksize][Cout] made by
+ * dvsof_weight_flip_transpose.  dst[i].p == NULL skips nothing (all sources
+ * are computed together); pass a scratch buffer if a gradient is not needed.
+ */
+int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *desc, const float *weight_t,
+                       const float *gout, const dvsof_grad_dst_t *dst,
+                       int bwd_act, void *stream);
+
+size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *desc);
+/* dweight [Cout][k][k][Ctot], dbias [Cout] (optional); overwritten. */
+int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *desc, const float *gout,
+                       float *dweight, float *dbias, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* wt[ci][k*k-1-tap][co] = w[co][tap][ci] */
+int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize,
+                                int Ctot, void *stream);
+
+/*
+ * Flow head: flow[b,j,y,x] = sum_c w[j][c] * x[b,y,x,c] + bias[j], j = 0,1.
+ * x NHWC [B,H,W,C] (C % 4 == 0), flow NCHW [B,2,H,W] (the layout the loss
+ * and the reference's prediction contract use, utils/training.py:59-64).
+ */
+int dvsof_flow_head_fwd(const float *x, const float *w, const float *bias,
+                        float *flow, int B, int H, int W, int C, void *stream);
+
+size_t dvsof_flow_head_bwd_workspace_bytes(int B, int H, int W, int C);
+/*
+ * Backward of the head fused with the activation backward of the decoder
+ * layer that produced x:
+ *   gx = (gx_in + w^T gflow) * act'(actsrc)      (gx_in optional, may alias gx)
+ *   dw[j][c] = sum gflow_j * x_c ,  dbias[j] = sum gflow_j
+ */
+int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow,
+                        const float *gx_in, const float *actsrc, int act,
+                        float *gx, float *dw, float *dbias, int B, int H, int W,
+                        int C, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* dz = dy * act'(actsrc), n elements (dz may alias dy) */
+int dvsof_act_bwd(const float *dy, const float *actsrc, int act, float *dz,
+                  size_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

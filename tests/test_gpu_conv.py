@@ -1,0 +1,182 @@
+"""HIP conv stack (through the C ABI) against plain PyTorch fp32 CPU ops.
+Tolerance: 1e-3 relative to the tensor's peak magnitude (north star: flow
+fields within 1e-3 relative fp32); typical error is ~1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def close(got, want, rtol=RTOL):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= rtol * ref + 1e-7, (err, ref)
+
+
+def nhwc(t):   # logical NCHW -> dense NHWC buffer on the GPU
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def from_nhwc(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def wphys(w):  # OIHW -> [O][kh][kw][I] on the GPU
+    return w.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+CASES = [
+    # B, H, W, chans(list, layouts), Cout, k, stride, up, act
+    dict(B=2, H=16, W=16, src=[(5, 'nchw')], Cout=64, stride=2),
+    dict(B=1, H=13, W=19, src=[(3, 'nchw')], Cout=32, stride=2),
+    dict(B=2, H=12, W=20, src=[(64, 'nhwc')], Cout=128, stride=2),
+    dict(B=3, H=8, W=8, src=[(32, 'nhwc')], Cout=32, stride=1, residual=True),
+    dict(B=2, H=8, W=12, src=[(32, 'nhwc'), (16, 'nhwc'), (2, 'nchw')], Cout=32,
+         up=True),
+    dict(B=1, H=4, W=4, src=[(512, 'nhwc'), (512, 'nhwc')], Cout=256, up=True),
+    dict(B=2, H=9, W=7, src=[(20, 'nhwc')], Cout=48, stride=1, k=5, pad=2),
+    dict(B=2, H=16, W=16, src=[(64, 'nhwc'), (64, 'nhwc'), (2, 'nchw')], Cout=32,
+         up=True, act='mish'),
+]
+
+
+def build(case, seed=0):
+    from dvs_of_training_framework_amd import conv as C
+    g = torch.Generator().manual_seed(seed)
+    B, H, W = case['B'], case['H'], case['W']
+    k, stride = case.get('k', 3), case.get('stride', 1)
+    pad, up = case.get('pad', 1), case.get('up', False)
+    act = {'relu': C.ACT_RELU, 'mish': C.ACT_MISH, 'none': C.ACT_NONE}[
+        case.get('act', 'relu')]
+    xs = [torch.randn(B, c, H, W, generator=g) for c, _ in case['src']]
+    ctot = sum(c for c, _ in case['src'])
+    w = torch.randn(case['Cout'], ctot, k, k, generator=g) / (ctot * k * k) ** 0.5
+    b = torch.randn(case['Cout'], generator=g)
+    dev = [(x.cuda().contiguous() if lay == 'nchw' else nhwc(x))
+           for x, (_, lay) in zip(xs, case['src'])]
+    srcs = [(d, c, C.NCHW if lay == 'nchw' else C.NHWC)
+            for d, (c, lay) in zip(dev, case['src'])]
+    desc = C.make_desc(srcs, B, H, W, case['Cout'], k, stride, pad, up, act)
+    return C, xs, w, b, desc, act, dict(k=k, stride=stride, pad=pad, up=up)
+
+
+def torch_fwd(xs, w, b, o, act, C, residual=None):
+    inp = torch.cat(xs, 1)
+    if o['up']:
+        inp = F.interpolate(inp, scale_factor=2, mode='nearest')
+    z = F.conv2d(inp, w, b, stride=o['stride'], padding=o['pad'])
+    if residual is not None:
+        z = z + residual
+    y = F.relu(z) if act == C.ACT_RELU else F.mish(z) if act == C.ACT_MISH else z
+    return y, z
+
+
+@pytest.mark.parametrize('ci', range(len(CASES)))
+def test_conv_fwd_dgrad_wgrad(ci):
+    case = CASES[ci]
+    C, xs, w, b, desc, act, o = build(case, seed=ci)
+    xs = [x.requires_grad_(True) for x in xs]
+    w.requires_grad_(True)
+    b.requires_grad_(True)
+    ho, wo = C.out_size(desc)
+    res = torch.randn(case['B'], case['Cout'], ho, wo) if case.get('residual') else None
+    y_ref, z_ref = torch_fwd(xs, w, b, o, act, C, res)
+    y, z = C.conv_fwd(desc, wphys(w), b.cuda(), 'cuda',
+                      nhwc(res) if res is not None else None, want_z=True)
+    close(from_nhwc(y), y_ref)
+    close(from_nhwc(z), z_ref)
+    # backward w.r.t. the pre-activation output
+    gz = torch.randn(z_ref.shape, generator=torch.Generator().manual_seed(99))
+    z_ref.backward(gz)
+    gz_d = nhwc(gz)
+    ctot = sum(c for c, _ in case['src'])
+    wt = C.flip_transpose(wphys(w.detach()), case['Cout'], o['k'], ctot)
+    dsts, holders = [], []
+    for x, (c, lay) in zip(xs, case['src']):
+        buf = torch.empty(x.shape if lay == 'nchw' else
+                          (x.shape[0], x.shape[2], x.shape[3], c), device='cuda')
+        holders.append((buf, lay))
+        dsts.append(dict(p=buf))
+    C.conv_dgrad(desc, wt, gz_d, dsts)
+    for (buf, lay), x in zip(holders, xs):
+        close(buf if lay == 'nchw' else from_nhwc(buf), x.grad)
+    dw = torch.empty(case['Cout'], o['k'], o['k'], ctot, device='cuda')
+    db = torch.empty(case['Cout'], device='cuda')
+    C.conv_wgrad(desc, gz_d, dw, db)
+    close(dw.permute(0, 3, 1, 2), w.grad)
+    close(db, b.grad)
+
+
+def test_dgrad_epilogue_addends_and_act():
+    from dvs_of_training_framework_amd import conv as C
+    case = dict(B=2, H=8, W=8, src=[(32, 'nhwc')], Cout=64, stride=2)
+    C, xs, w, b, desc, act, o = build(case, seed=3)
+    x = xs[0].requires_grad_(True)
+    _, z_ref = torch_fwd([x], w, b, o, act, C)
+    gz = torch.randn(z_ref.shape)
+    z_ref.backward(gz)
+    a1, a2 = torch.randn(x.shape), torch.randn(x.shape)
+    ysrc = torch.randn(x.shape)
+    want = (x.grad + a1 + a2) * (ysrc > 0).float()
+    buf = torch.empty(2, 8, 8, 32, device='cuda')
+    wt = C.flip_transpose(wphys(w), 64, 3, 32)
+    C.conv_dgrad(desc, wt, nhwc(gz), [dict(p=buf, addend=nhwc(a1), addend2=nhwc(a2),
+                                           actsrc=nhwc(ysrc))], C.ACT_RELU)
+    close(from_nhwc(buf), want)
+
+
+@pytest.mark.parametrize('Cc,act', [(32, 'relu'), (256, 'relu'), (64, 'mish')])
+def test_flow_head(Cc, act):
+    from dvs_of_training_framework_amd import conv as C
+    B, H, W = 2, 12, 20
+    aid = C.ACT_RELU if act == 'relu' else C.ACT_MISH
+    x = torch.randn(B, Cc, H, W, requires_grad=True)
+    w = (torch.randn(2, Cc, 1, 1) / Cc ** 0.5).requires_grad_(True)
+    b = torch.randn(2, requires_grad=True)
+    zsrc = torch.randn(B, Cc, H, W)      # stand-in for the producer's y / z
+    f_ref = F.conv2d(x, w, b)
+    f = C.head_fwd(nhwc(x), w.view(2, Cc).cuda().contiguous(), b.cuda(), B, H, W, Cc)
+    close(f, f_ref)
+    gf, gx_in = torch.randn(f_ref.shape), torch.randn(x.shape)
+    f_ref.backward(gf)
+    dact = (zsrc > 0).float() if act == 'relu' else \
+        torch.autograd.grad(F.mish(zsrc.requires_grad_(True)).sum(), zsrc)[0]
+    want_gx = (x.grad + gx_in) * dact
+    gx = torch.empty(B, H, W, Cc, device='cuda')
+    dw, db = torch.empty(2, Cc, device='cuda'), torch.empty(2, device='cuda')
+    C.head_bwd(nhwc(x), w.view(2, Cc).cuda().contiguous(), gf.cuda(), nhwc(gx_in),
+               nhwc(zsrc.detach()), aid, gx, dw, db, B, H, W, Cc)
+    close(from_nhwc(gx), want_gx)
+    close(dw, w.grad.view(2, Cc))
+    close(db, b.grad)
+
+
+@pytest.mark.parametrize('mish', [False, True])
+def test_predictor_vs_torch_reference(mish):
+    """Whole predictor forward + backward (explicit schedule) vs ATen autograd."""
+    from dvs_of_training_framework_amd.predictor import Predictor
+    from tests.ref_model import ref_predictor
+    torch.manual_seed(1)
+    B, Cin, H, W = 2, 5, 32, 48
+    act = torch.nn.Mish() if mish else torch.nn.ReLU()
+    net = Predictor(Cin, act)
+    x = torch.randn(B, Cin, H, W)
+    state = {k: v.detach().clone().requires_grad_(True)
+             for k, v in net.state_dict().items()}
+    ref_flows = ref_predictor(state, x, mish)
+    gfl = [torch.randn(f.shape) for f in ref_flows]
+    sum((f * g).sum() for f, g in zip(ref_flows, gfl)).backward()
+    net = net.cuda()
+    flows = net(x.cuda())
+    assert [tuple(f.shape) for f in flows] == [(B, 2, H // 8, W // 8), (B, 2, H // 4, W // 4),
+                                               (B, 2, H // 2, W // 2), (B, 2, H, W)]
+    for f, r in zip(flows, ref_flows):
+        close(f, r, 1e-3)
+    sum((f * g.cuda()).sum() for f, g in zip(flows, gfl)).backward()
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        close(p.grad, state[name].grad, 1e-3)
