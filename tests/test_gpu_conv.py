@@ -61,6 +61,7 @@ def build(case, seed=0):
     srcs = [(d, c, C.NCHW if lay == 'nchw' else C.NHWC)
             for d, (c, lay) in zip(dev, case['src'])]
     desc = C.make_desc(srcs, B, H, W, case['Cout'], k, stride, pad, up, act)
+    desc._keepalive = dev   # the descriptor only holds raw pointers
     return C, xs, w, b, desc, act, dict(k=k, stride=stride, pad=pad, up=up)
 
 
