@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/s of the optical-flow hot path
+(BASELINE.json: EV_FlowNet on synthetic 256x256x5-bin event tensors,
+batch 8 per GPU, fp32; configs[1] at N=1, weak scaling for N>1).
+
+One step = voxelise the event batch -> predictor forward -> fused multi-scale
+loss -> backward (dgrad/wgrad on the matrix cores) -> [RCCL gradient
+all-reduce, overlapped] -> fused AdamW-amsgrad step.  Inputs are resident in
+HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying
+`roofline` (dominant kernel: algorithmic FLOPs / HIP-event time, measured on
+the launch stream) and, at N=1, `cpu_baseline` (the CPU port of the same step
+timed on the host cores over a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+TILE_NAMES = {
+    'gconv': {1: 'gconv_kernel<2,2,2,2> 128x128', 2: 'gconv_kernel<2,2,2,1> 128x64',
+              3: 'gconv_kernel<2,2,1,1> 64x64', 4: 'gconv_kernel<4,1,2,1> 256x32',
+              5: 'gconv_kernel<4,1,1,1> 128x32'},
+    'wgrad': {1: 'wgrad_kernel<2,2,2,2> 128x128', 2: 'wgrad_kernel<2,2,2,1> 128x64',
+              3: 'wgrad_kernel<2,2,1,1> 64x64', 4: 'wgrad_kernel<2,2,1,2> 64x128',
+              5: 'wgrad_kernel<1,4,1,1> 32x128'},
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=30)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=8, help='samples per GPU')
+    p.add_argument('--height', type=int, default=256)
+    p.add_argument('--width', type=int, default=256)
+    p.add_argument('--bins', type=int, default=5)
+    p.add_argument('--events', type=int, default=None,
+                   help='events per sample (default H*W, SURVEY 8d)')
+    p.add_argument('--pool', type=int, default=2,
+                   help='distinct resident batches cycled through')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--cpu-samples', type=int, default=2)
+    return p.parse_args()
+
+
+class Harness:
+    def __init__(self, a, rank, device):
+        from dvs_of_training_framework_amd import synthetic
+        from dvs_of_training_framework_amd.loss import init_losses
+        from dvs_of_training_framework_amd.net import Model
+        from dvs_of_training_framework_amd.optim import FusedAdamW
+        torch.manual_seed(1234)            # identical replicas
+        self.a, self.device = a, device
+        self.model = Model(device, event_representation_depth=a.bins)
+        self.model.train()
+        self.opt = FusedAdamW(self.model.predictor.parameters(), lr=1e-3,
+                              weight_decay=1e-4, amsgrad=True)
+        self.sched = torch.optim.lr_scheduler.LambdaLR(
+            self.opt, lambda s: 2 ** (-s / 100000))
+        self.losses = init_losses((a.height, a.width), a.batch, self.model,
+                                  device, sequence_length=1)
+        self.batches = [synthetic.to_torch(synthetic.make_batch(
+            1234 + rank + 1000 * i, a.batch, a.height, a.width, a.events),
+            device) for i in range(a.pool)]
+        self.reducer = None
+        self.i = 0
+
+    def step(self):
+        from dvs_of_training_framework_amd.timer import FakeTimer
+        from dvs_of_training_framework_amd.training import process_minibatch
+        batch = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        loss, terms, tags = process_minibatch(
+            self.model, batch, FakeTimer(), self.device, True, self.losses,
+            [0.5, 1, 1])
+        loss.backward()
+        self.model.strict = False
+        if self.reducer is not None:
+            self.reducer.wait()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        self.sched.step()
+        return loss
+
+
+def conv_flops(desc, kind):
+    from dvs_of_training_framework_amd import conv as C
+    ho, wo = C.out_size(desc)
+    ctot = sum(desc.src[i].C for i in range(desc.nsrc))
+    return 2.0 * desc.B * ho * wo * desc.Cout * ctot * desc.ksize ** 2
+
+
+def measure_roofline(h, steps=3):
+    """Per-launch HIP-event timing of every conv-stack launch on torch's
+    current stream (= the launch stream); groups by kernel template."""
+    from dvs_of_training_framework_amd import conv as C
+    lib = C._lib.lib()
+    records = []
+    orig = (C.conv_fwd, C.conv_dgrad, C.conv_wgrad)
+
+    def wrap(fn, kind, family):
+        def inner(desc, *args, **kw):
+            import ctypes
+            tile = lib.dvsof_conv2d_tile_id(ctypes.byref(desc), kind)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(desc, *args, **kw)
+            e1.record()
+            records.append((TILE_NAMES[family][tile], conv_flops(desc, kind),
+                            e0, e1))
+            return out
+        return inner
+    C.conv_fwd = wrap(orig[0], 0, 'gconv')
+    C.conv_dgrad = wrap(orig[1], 1, 'gconv')
+    C.conv_wgrad = wrap(orig[2], 2, 'wgrad')
+    try:
+        for _ in range(steps):
+            h.step()
+        torch.cuda.synchronize()
+    finally:
+        C.conv_fwd, C.conv_dgrad, C.conv_wgrad = orig
+    agg = {}
+    for name, fl, e0, e1 in records:
+        d = agg.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += fl
+        d[2] += e0.elapsed_time(e1) * 1e-3
+    table = {k: dict(launches=v[0] // steps, gflop_per_step=v[1] / steps / 1e9,
+                     ms_per_step=v[2] / steps * 1e3,
+                     tflops=v[1] / v[2] / 1e12) for k, v in agg.items()}
+    dom = max(agg, key=lambda k: agg[k][2])
+    n, fl, sec = agg[dom]
+    total_fl = sum(v[1] for v in agg.values())
+    total_s = sum(v[2] for v in agg.values())
+    roof = {'bound': 'mfma', 'kernel': dom,
+            'achieved': round(fl / sec / 1e12, 2),
+            'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(fl / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+            'traffic': None,
+            'avg_launch_us': round(sec / n * 1e6, 2),
+            'gflop_per_launch': round(fl / n / 1e9, 3),
+            'conv_stack_tflops': round(total_fl / total_s / 1e12, 2),
+            'conv_stack_frac': round(total_fl / total_s / 1e12 /
+                                     PEAK_F32_MATRIX_TFLOPS, 4),
+            'per_kernel': {k: {kk: round(vv, 3) for kk, vv in v.items()}
+                           for k, v in table.items()}}
+    return roof
+
+
+def cpu_baseline(a):
+    """CPU port of the same training step (oracle/: C voxeliser + loss,
+    PyTorch-CPU restatement of the predictor, torch AdamW), timed on the host
+    cores over a bounded sample of the workload."""
+    import numpy as np
+    from oracle import cpu_oracle as orc
+    from oracle.ref_model import ref_predictor
+    from dvs_of_training_framework_amd import synthetic
+    from dvs_of_training_framework_amd.predictor import Predictor
+    cores = torch.get_num_threads()
+    B = max(1, min(a.cpu_samples, a.batch))
+    torch.manual_seed(1234)
+    net = Predictor(a.bins)
+    state = {k: v.detach().clone().requires_grad_(True)
+             for k, v in net.state_dict().items()}
+    opt = torch.optim.AdamW(list(state.values()), lr=1e-3, weight_decay=1e-4,
+                            amsgrad=True)
+    batch = synthetic.make_batch(1234, B, a.height, a.width, a.events)
+    shapes = synthetic.scale_shapes(a.height, a.width)
+
+    def step():
+        t0 = np.zeros(B, np.float32)
+        t1 = np.full(B, synthetic.WINDOW, np.float32)
+        grid, _, _ = orc.voxelize(batch['events'], t0, t1, B, a.bins,
+                                  a.height, a.width)
+        flows = ref_predictor(state, torch.from_numpy(grid))
+        ts = batch['timestamps'].reshape(B, 2)
+        _, loss, grads = orc.losses(
+            [f.detach().numpy() for f in flows], ts, np.arange(B),
+            batch['images'], batch['timestamps'], batch['sample_idx'])
+        torch.autograd.backward(flows, [torch.from_numpy(g) for g in grads])
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+    step()                                  # warm-up
+    n, t = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t < 10 and n < 20):
+        step()
+        n += 1
+    dt = time.perf_counter() - t
+    return {'value': round(B * n / dt, 3), 'unit': 'samples/s', 'cores': cores,
+            'kind': 'port',
+            'sample': f'{n} steps of batch {B} (of {a.batch}) at '
+                      f'{a.height}x{a.width}x{a.bins}, {dt:.1f} s, '
+                      f'torch {cores} threads + scalar C loss/voxel'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    from dvs_of_training_framework_amd import parallel
+    rank, local, world = parallel.init_distributed('cuda')
+    if world != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with '
+                         'torch.distributed.run --nproc-per-node N')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    h = Harness(a, rank, device)
+    if world > 1:
+        parallel.broadcast_parameters(h.model)
+        h.reducer = parallel.GradReducer()
+        h.model.predictor.reducer = h.reducer
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    for _ in range(a.warmup):
+        h.step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = h.step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+
+    out = None
+    if rank == 0:
+        gb = a.batch * world
+        out = {
+            'metric': 'training samples/sec (256x256x5 event voxels)',
+            'value': round(gb * a.steps / dt, 2), 'unit': 'samples/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': f'EV_FlowNet {a.height}x{a.width}x{a.bins}-bin '
+                            f'synthetic events, batch {a.batch} per GPU, fp32 '
+                            '(BASELINE.json configs[1]); full step: voxelise + '
+                            'fwd + multi-scale loss + bwd + AdamW-amsgrad',
+                'global_batch': gb, 'events_per_sample':
+                    a.events or a.height * a.width,
+                'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
+        }
+    if not a.no_roofline:
+        roof = measure_roofline(h)          # every rank runs the same steps
+        if rank == 0:
+            out['roofline'] = roof
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

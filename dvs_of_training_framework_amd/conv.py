@@ -48,6 +48,7 @@ _lib.register('dvsof_flow_head_bwd', _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp,
                                           _vp, _vp, _i, _i, _i, _i, _vp, _sz,
                                           _vp])
 _lib.register('dvsof_act_bwd', _i, [_vp, _vp, _i, _vp, _sz, _vp])
+_lib.register('dvsof_conv2d_tile_id', _i, [_P(ConvDesc), _i])
 
 
 def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,

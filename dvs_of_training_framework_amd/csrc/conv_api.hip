@@ -7,6 +7,8 @@
 int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st);
 int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats, hipStream_t st);
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias);
+int gconv_pick_tile(long long m, long long n);
+int wgrad_splits(const WGradParams &P0, int *tile_out);
 
 namespace {
 
@@ -344,6 +346,25 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
     P.gout = gout;
     if (wgrad_workspace_floats(P, dbias != nullptr) > 0 && !ws) return DVSOF_ENOSPACE;
     return wgrad_launch(P, dweight, dbias, (float *)ws, ws_bytes / sizeof(float), as_stream(stream));
+}
+
+int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo)) return DVSOF_EINVAL;
+    if (kind == 0) return gconv_pick_tile((long long)d->B * Ho * Wo, d->Cout);
+    if (kind == 1) {
+        const int up = d->upsample ? 2 : 1;
+        return gconv_pick_tile((long long)d->B * d->H * up * d->W * up, Ctot);
+    }
+    if (kind == 2) {
+        WGradParams P;
+        fill_wgrad(d, Ctot, Ho, Wo, P);
+        int tile = 0;
+        wgrad_splits(P, &tile);
+        return tile;
+    }
+    return DVSOF_EINVAL;
 }
 
 int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize, int Ctot,

@@ -313,6 +313,16 @@ int launch(const GConvParams &P, hipStream_t st)
 
 }  // namespace
 
+// largest tile that still gives every CU work (256 CUs)
+int gconv_pick_tile(long long m, long long n)
+{
+    auto blocks = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
+    if (n <= 32) return blocks(256, 32) >= 512 ? 4 : 5;
+    if (n >= 128 && blocks(128, 128) >= 512) return 1;
+    if (blocks(128, 64) >= 512) return 2;
+    return 3;
+}
+
 // Internal entry (not part of the C ABI): picks the tile shape and launches.
 int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
 {
@@ -322,16 +332,7 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
     if (P.stride != 1 && P.stride != 2) return DVSOF_EINVAL;
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
-    int tile = tile_hint;
-    if (tile <= 0) {
-        // largest tile that still gives every CU work (256 CUs)
-        const long long m = P.M, n = P.N;
-        auto blocks = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
-        if (n <= 32) tile = blocks(256, 32) >= 512 ? 4 : 5;
-        else if (n >= 128 && blocks(128, 128) >= 512) tile = 1;
-        else if (blocks(128, 64) >= 512) tile = 2;
-        else tile = 3;
-    }
+    const int tile = tile_hint > 0 ? tile_hint : gconv_pick_tile(P.M, P.N);
     switch (tile) {
     case 1: return launch<2, 2, 2, 2>(P, st);  // 128 x 128
     case 2: return launch<2, 2, 2, 1>(P, st);  // 128 x 64

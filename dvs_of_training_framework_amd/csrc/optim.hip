@@ -1,0 +1,111 @@
+// Fused multi-tensor AdamW (amsgrad) step: one launch per parameter group.
+// Replaces torch.optim.AdamW(amsgrad=True).step() as constructed at
+// train_flownet.py:57-75 and called at utils/training.py:164 (foreach /
+// unfused ATen ops: ~10 launches per tensor).  HBM-bound: reads p,g,m,v,vmax,
+// writes p,m,v,vmax = 36 B per parameter.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct AdamArgs {
+    float lr, beta1, beta2, eps, weight_decay;
+    float step_size;  // lr / (1 - beta1^t)
+    float bc2_sqrt;   // sqrt(1 - beta2^t)
+    int amsgrad;
+};
+
+constexpr int CHUNK = 4096;  // elements per workgroup
+
+// op order of torch.optim.adam._single_tensor_adam (decoupled weight decay)
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float &vm,
+                                          const AdamArgs &a)
+{
+    p = p * (1.f - a.lr * a.weight_decay);
+    m = m + (g - m) * (1.f - a.beta1);           // lerp_
+    v = v * a.beta2 + (1.f - a.beta2) * g * g;   // mul_().addcmul_()
+    float denom;
+    if (a.amsgrad) {
+        vm = fmaxf(vm, v);
+        denom = sqrtf(vm) / a.bc2_sqrt + a.eps;
+    } else {
+        denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    }
+    p = p - a.step_size * (m / denom);
+}
+
+// table: per tensor {p, g, m, v, vmax} pointers and element count; chunk
+// table: (tensor id, chunk index) per workgroup.
+__global__ __launch_bounds__(256) void adamw_kernel(const uint64_t *__restrict__ ptrs,
+                                                    const int64_t *__restrict__ sizes,
+                                                    const int32_t *__restrict__ chunks,
+                                                    const AdamArgs a)
+{
+    const int t = chunks[2 * blockIdx.x], c = chunks[2 * blockIdx.x + 1];
+    float *p = (float *)ptrs[5 * t + 0];
+    const float *g = (const float *)ptrs[5 * t + 1];
+    float *m = (float *)ptrs[5 * t + 2];
+    float *v = (float *)ptrs[5 * t + 3];
+    float *vm = (float *)ptrs[5 * t + 4];
+    const int64_t n = sizes[t];
+    const int64_t base = (int64_t)c * CHUNK;
+#pragma unroll
+    for (int it = 0; it < CHUNK / 1024; ++it) {
+        const int64_t i = base + it * 1024 + threadIdx.x * 4;
+        if (i + 3 < n) {
+            f32x4 P = *(f32x4u *)(p + i), G = *(const f32x4u *)(g + i);
+            f32x4 M = *(f32x4u *)(m + i), V = *(f32x4u *)(v + i);
+            f32x4 X = a.amsgrad ? *(f32x4u *)(vm + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = P[j], mj = M[j], vj = V[j], xj = X[j];
+                adam_elem(pj, G[j], mj, vj, xj, a);
+                P[j] = pj; M[j] = mj; V[j] = vj; X[j] = xj;
+            }
+            *(f32x4u *)(p + i) = P;
+            *(f32x4u *)(m + i) = M;
+            *(f32x4u *)(v + i) = V;
+            if (a.amsgrad) *(f32x4u *)(vm + i) = X;
+        } else {
+            for (int64_t j = i; j < n && j < i + 4; ++j) {
+                float x = a.amsgrad ? vm[j] : 0.f;
+                adam_elem(p[j], g[j], m[j], v[j], x, a);
+                if (a.amsgrad) vm[j] = x;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvsof_adamw_chunk_elems(void) { return CHUNK; }
+
+int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes, const int32_t *chunks,
+                     int num_chunks, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, int amsgrad, void *stream)
+{
+    if (!ptrs || !sizes || !chunks || num_chunks < 0 || step < 1) return DVSOF_EINVAL;
+    if (num_chunks == 0) return DVSOF_OK;
+    AdamArgs a;
+    a.lr = lr;
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    // bias corrections in double like the Python reference (python floats)
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.amsgrad = amsgrad;
+    hipLaunchKernelGGL(adamw_kernel, dim3(num_chunks), dim3(256), 0, as_stream(stream), ptrs, sizes,
+                       chunks, a);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI.
+
+The reference is single-process (no torch.distributed
+use at all); this is the new capability behind the same train loop.  The
+predictor's explicit backward hands over gradient BUCKETS (flat buffers, in
+the order the backward produces them: fine decoder stages first, encoder
+last) as soon as the last wgrad of a bucket has been enqueued; each bucket is
+all-reduced (average) on a side HIP stream gated by an event, so the exchange
+overlaps the rest of the backward.  ``wait()`` makes the compute stream wait
+for the outstanding collectives right before the optimizer step.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(device_type='cuda'):
+    """Initialise from the torchrun environment (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR, MASTER_PORT).  -> (rank, local_rank, world_size)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = 'nccl' if device_type == 'cuda' else 'gloo'
+        if device_type == 'cuda':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class GradReducer:
+    """Averages gradient buckets across ranks, overlapped with backward."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.enabled = True          # False on non-boundary micro-batches
+        self.pending = []
+        self._side = None
+        self.bytes_reduced = 0
+
+    def _side_stream(self, device):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def bucket_ready(self, flat):
+        if not self.enabled or self.world == 1:
+            return
+        self.bytes_reduced += flat.numel() * flat.element_size()
+        if flat.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+            side = self._side_stream(flat.device)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG,
+                                       group=self.group, async_op=True)
+            self.pending.append((work, flat, False))
+        else:   # gloo (CPU tests): SUM then scale
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM,
+                                   group=self.group, async_op=True)
+            self.pending.append((work, flat, True))
+
+    def wait(self):
+        for work, flat, scale in self.pending:
+            work.wait()          # NCCL: the current stream waits, not the host
+            if scale:
+                flat.div_(self.world)
+        self.pending = []
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Replicas start from rank ``src``'s weights."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def all_reduce_scalars(t, group=None):
+    """Average a small tensor of logged scalars across ranks (optional)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+    return t

@@ -78,9 +78,10 @@ def _phys(w):
 
 class _PredictorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, act, want_grad, *params):
+    def forward(ctx, x0, module, want_grad, *params):
         # params: enc(w,b)x4, res(w1,b1,w2,b2)x2, dec(w,b,fw,fb)x4
         dev = x0.device
+        act = module.act
         B, Cin, H, W = x0.shape
         mish = act == C.ACT_MISH
         p = list(params)
@@ -126,7 +127,7 @@ class _PredictorFn(torch.autograd.Function):
         if want_grad:
             ctx.L, ctx.act, ctx.dims = L, act, (B, Cin, H, W)
             ctx.params = params
-            ctx.flows = flows
+            ctx.module = module
         return tuple(flows)
 
     @staticmethod
@@ -135,7 +136,7 @@ class _PredictorFn(torch.autograd.Function):
         params = ctx.params
         dev = gflows[0].device
         mish = act == C.ACT_MISH
-        grads = [torch.empty_like(q) for q in params]
+        grads, finish = ctx.module._grad_targets(params)
         gflows = [g.contiguous() for g in gflows]
 
         def asrc(layer):        # what act' is evaluated on
@@ -167,6 +168,7 @@ class _PredictorFn(torch.autograd.Function):
             C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
                        grads[pfw], grads[pfb], B, h, w, d.Cout)
             C.conv_wgrad(d, gz, grads[pw], grads[pb])
+            finish(('dec', i))
             srcs = lay['srcs']
             g_in = new(srcs[0][0])
             g_e = new(srcs[1][0])
@@ -189,10 +191,12 @@ class _PredictorFn(torch.autograd.Function):
             l1, l2 = res_l[2 * i], res_l[2 * i + 1]
             pw1, pb1, pw2, pb2 = (po_res + 4 * i + j for j in range(4))
             C.conv_wgrad(l2['desc'], gs, grads[pw2], grads[pb2])
+            finish(('res', i, 2))
             g_t = new(l1['y'])
             C.conv_dgrad(l2['desc'], wt(l2), gs,
                          [dict(p=g_t, actsrc=asrc(l1))], act)
             C.conv_wgrad(l1['desc'], g_t, grads[pw1], grads[pb1])
+            finish(('res', i, 1))
             below = res_l[2 * i - 1] if i > 0 else enc_l[3]
             g_prev = new(below['y'])
             dst = dict(p=g_prev, addend=gs, actsrc=asrc(below))
@@ -205,6 +209,7 @@ class _PredictorFn(torch.autograd.Function):
         for i in (3, 2, 1, 0):
             lay = enc_l[i]
             C.conv_wgrad(lay['desc'], gz, grads[2 * i], grads[2 * i + 1])
+            finish(('enc', i))
             if i == 0:
                 break
             below = enc_l[i - 1]
@@ -214,7 +219,7 @@ class _PredictorFn(torch.autograd.Function):
                                actsrc=asrc(below))], act)
             gz = g_prev
         ctx.L = None
-        return (None, None, None) + tuple(grads)
+        return (None,) * (3 + len(params))
 
 
 class Predictor(nn.Module):
@@ -222,6 +227,7 @@ class Predictor(nn.Module):
         super().__init__()
         self.in_channels = in_channels
         self.act = activation_id(activation)
+        self.reducer = None      # parallel.GradReducer for data parallelism
         chans = (in_channels,) + ENC_CH
         self.enc = nn.ModuleList(
             _Named(conv=ConvParams(chans[i], chans[i + 1], 3))
@@ -234,6 +240,81 @@ class Predictor(nn.Module):
             _Named(conv=ConvParams(dec_in[i], DEC_CH[i], 3),
                    flow=ConvParams(DEC_CH[i], 2, 1))
             for i in range(4))
+
+    # Gradient buckets in the order the backward completes them (fine decoder
+    # stages first, encoder last): persistent flat buffers that the wgrad
+    # kernels write into, that ``p.grad`` views, that the DP reducer
+    # all-reduces and that the fused optimizer reads.
+    UNIT_PARAMS = {
+        **{('dec', i): tuple(8 + 4 * NUM_RES + 4 * i + j for j in range(4))
+           for i in range(4)},
+        **{('res', i, 2): (8 + 4 * i + 2, 8 + 4 * i + 3) for i in range(NUM_RES)},
+        **{('res', i, 1): (8 + 4 * i, 8 + 4 * i + 1) for i in range(NUM_RES)},
+        **{('enc', i): (2 * i, 2 * i + 1) for i in range(4)},
+    }
+    BUCKETS = (
+        (('dec', 3), ('dec', 2), ('dec', 1)),
+        (('dec', 0),),
+        (('res', 1, 2),), (('res', 1, 1),), (('res', 0, 2),), (('res', 0, 1),),
+        (('enc', 3),),
+        (('enc', 2), ('enc', 1), ('enc', 0)),
+    )
+
+    def _buckets(self, params):
+        dev = params[0].device
+        key = (dev, tuple(p.numel() for p in params))
+        if getattr(self, '_bucket_key', None) != key:
+            self._bucket_key = key
+            self._bucket_flat, self._bucket_slot = [], {}
+            for b, units in enumerate(self.BUCKETS):
+                off = 0
+                for u in units:
+                    for i in self.UNIT_PARAMS[u]:
+                        self._bucket_slot[i] = (b, off)
+                        off += params[i].numel()
+                self._bucket_flat.append(
+                    torch.empty(off, dtype=torch.float32, device=dev))
+        return self._bucket_flat, self._bucket_slot
+
+    def _grad_targets(self, params):
+        """-> (targets, finish): per-parameter tensors the backward writes
+        into, and a callback to call when a unit's gradients are enqueued.
+        A parameter without .grad gets a view of its bucket as .grad; one that
+        already has a gradient (micro-batch accumulation,
+        reference utils/training.py:156-167) is accumulated into."""
+        flats, slot = self._buckets(params)
+        views, targets, accumulate = [], [], []
+        for i, p in enumerate(params):
+            b, off = slot[i]
+            v = flats[b][off:off + p.numel()].as_strided(p.shape, p.stride())
+            views.append(v)
+            if p.grad is None:
+                targets.append(v)
+                accumulate.append(False)
+            else:
+                targets.append(torch.empty_like(p))
+                accumulate.append(True)
+        remaining = [len(units) for units in self.BUCKETS]
+        unit_bucket = {u: b for b, units in enumerate(self.BUCKETS)
+                       for u in units}
+        reducer = self.reducer
+
+        def finish(unit):
+            for i in self.UNIT_PARAMS[unit]:
+                p = params[i]
+                if accumulate[i]:
+                    p.grad.add_(targets[i])
+                else:
+                    p.grad = views[i]
+            b = unit_bucket[unit]
+            remaining[b] -= 1
+            if remaining[b] == 0 and reducer is not None:
+                owned = all(params[i].grad.data_ptr() == views[i].data_ptr()
+                            for u in self.BUCKETS[b]
+                            for i in self.UNIT_PARAMS[u])
+                assert owned, 'DP needs .grad to live in the bucket buffers'
+                reducer.bucket_ready(flats[b])
+        return targets, finish
 
     def param_list(self):
         out = []
@@ -255,7 +336,7 @@ class Predictor(nn.Module):
         params = self.param_list()
         want_grad = torch.is_grad_enabled() and any(p.requires_grad
                                                     for p in params)
-        return _PredictorFn.apply(voxels.contiguous(), self.act, want_grad,
+        return _PredictorFn.apply(voxels.contiguous(), self, want_grad,
                                   *params)
 
     def flops_per_sample(self, H, W):

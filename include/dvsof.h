@@ -200,6 +200,14 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *desc, const float *gout,
                        float *dweight, float *dbias, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+
+/*
+ * Which tile shape the library picks for this problem (for profiling tools):
+ * kind 0 = forward, 1 = data gradient, 2 = weight gradient.  Returns the
+ * tile id (1..5: 128x128, 128x64, 64x64, 256x32|64x128, 128x32|32x128) or <0.
+ */
+int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *desc, int kind);
+
 /* wt[ci][k*k-1-tap][co] = w[co][tap][ci] */
 int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize,
                                 int Ctot, void *stream);
@@ -228,6 +236,30 @@ int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow,
 /* dz = dy * act'(actsrc), n elements (dz may alias dy) */
 int dvsof_act_bwd(const float *dy, const float *actsrc, int act, float *dz,
                   size_t n, void *stream);
+
+
+/* ------------------------------------------------------------------ *
+ * Optimizer
+ * ------------------------------------------------------------------ */
+
+/* elements one workgroup of dvsof_adamw_step handles (chunk table unit) */
+int dvsof_adamw_chunk_elems(void);
+
+/*
+ * Fused multi-tensor AdamW step (decoupled weight decay, optional amsgrad) for
+ * one parameter group.  Replaces torch.optim.AdamW(amsgrad=True).step() as
+ * built at train_flownet.py:57-75 and called at utils/training.py:164.
+ *   ptrs    device uint64[5*T]: {param, grad, exp_avg, exp_avg_sq,
+ *           max_exp_avg_sq} pointers of tensor t (float32, dense)
+ *   sizes   device int64[T]: element counts
+ *   chunks  device int32[2*num_chunks]: (tensor id, chunk index) per
+ *           workgroup, chunk = dvsof_adamw_chunk_elems() elements
+ *   step    1-based step count (bias correction)
+ */
+int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes,
+                     const int32_t *chunks, int num_chunks, float lr,
+                     float beta1, float beta2, float eps, float weight_decay,
+                     int step, int amsgrad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,6 @@
-"""Plain PyTorch fp32 restatement of docs/MODEL_SPEC.md (CPU or GPU, ATen ops
+"""TEST INFRASTRUCTURE ONLY (see oracle/dvsof_oracle.c header).
+
+Plain PyTorch fp32 restatement of docs/MODEL_SPEC.md (CPU or GPU, ATen ops
 only) -- the floating-point reference the HIP conv stack is compared with.
 Upstream's EV_FlowNet source is absent ("parity unpinned"), so this
 file and the spec define the network; it takes the SAME state_dict as

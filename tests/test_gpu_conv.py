@@ -160,7 +160,7 @@ def test_flow_head(Cc, act):
 def test_predictor_vs_torch_reference(mish):
     """Whole predictor forward + backward (explicit schedule) vs ATen autograd."""
     from dvs_of_training_framework_amd.predictor import Predictor
-    from tests.ref_model import ref_predictor
+    from oracle.ref_model import ref_predictor
     torch.manual_seed(1)
     B, Cin, H, W = 2, 5, 32, 48
     act = torch.nn.Mish() if mish else torch.nn.ReLU()

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Training entry point with the reference's flags and wiring
+(train_flownet.py:31-217): model plugin -> optimizer + LambdaLR ->
+``init_losses`` -> ``train``.  Additions: one process per GPU under torchrun
+(RCCL gradient all-reduce overlapped with backward) and ``--synthetic``.
+
+The reference's HDF5 data pipeline, TensorBoard writer, serializer and hooks
+are outside this build's scope: when this file is
+dropped into the reference tree they are imported from there (``utils.*``);
+otherwise ``--synthetic`` supplies batches in the same wire format.
+"""
+import sys
+from argparse import ArgumentParser
+from pathlib import Path
+
+import torch
+import torch.optim as optim
+
+from dvs_of_training_framework_amd import parallel, synthetic
+from dvs_of_training_framework_amd.loss import init_losses
+from dvs_of_training_framework_amd.model import init_model
+from dvs_of_training_framework_amd.optim import FusedAdamW
+from dvs_of_training_framework_amd.options import (
+    add_train_arguments, add_preprocessed_dataset_arguments,
+    validate_train_args)
+from dvs_of_training_framework_amd.timer import EventTimer, FakeTimer
+from dvs_of_training_framework_amd.training import train
+
+script_dir = Path(__file__).resolve().parent
+
+
+def parse_args(argv):
+    parser = ArgumentParser()
+    parser = add_train_arguments(parser)
+    parser = add_preprocessed_dataset_arguments(parser)
+    args = parser.parse_args(argv)
+    args = validate_train_args(args)
+    args.model.mkdir(exist_ok=True, parents=True)
+    args.log_path = args.model / 'log'
+    return args
+
+
+def get_params2optimize(model):            # train_flownet.py:50-54
+    if hasattr(model, 'quantization_layer'):
+        return [{'params': model.quantization_layer.parameters()},
+                {'params': model.predictor.parameters()}]
+    return [{'params': model.parameters()}]
+
+
+def construct_optimizer(args, params):     # train_flownet.py:57-75
+    for g in params:
+        g['params'] = list(g['params'])
+    params = [g for g in params if g['params']]   # e.g. parameter-free voxeliser
+    if args.optimizer == 'ADAM':
+        on_gpu = all(p.is_cuda for g in params for p in g['params'])
+        opt = FusedAdamW if on_gpu else optim.AdamW
+        return opt(params, lr=args.lr, weight_decay=args.wdw, amsgrad=True)
+    if args.optimizer in ('RADAM', 'RANGER'):
+        # un-vendored submodules upstream (RAdam/, Ranger-Deep-Learning-
+        # Optimizer/): SURVEY.md section 8f rank 1, not built yet
+        raise NotImplementedError(
+            f'--optimizer {args.optimizer} is not available in this build; '
+            'use --optimizer ADAM')
+    assert hasattr(torch.optim, args.optimizer), 'Unknown optimizer type'
+    return getattr(torch.optim, args.optimizer)(params, lr=args.lr,
+                                                weight_decay=args.wdw)
+
+
+def make_schedulers(args):                 # train_flownet.py:91-99
+    representation_start = args.training_steps * args.rs
+
+    def pred_scheduler(step):
+        if step < args.num_warmup_steps:
+            return step / args.num_warmup_steps
+        return 2 ** (-(step - args.num_warmup_steps) / args.half_life)
+
+    def repr_scheduler(step):
+        if step > representation_start:
+            return pred_scheduler(step)
+        return 0
+    return pred_scheduler, repr_scheduler
+
+
+def construct_train_tools(args, model, passed_steps=0):   # :78-109
+    is_splitted = hasattr(model, 'quantization_layer')
+    if is_splitted:
+        representation_params = [{
+            'params': list(model.quantization_layer.parameters()),
+            'weight_decay': args.wdw}]
+        predictor_params = [{'params': list(model.predictor.parameters())}]
+    else:
+        representation_params = []
+        predictor_params = [{'params': list(model.parameters()),
+                             'weight_decay': args.wdw}]
+    pred_scheduler, repr_scheduler = make_schedulers(args)
+    groups = representation_params + predictor_params
+    lambdas = [repr_scheduler] * len(representation_params) + \
+        [pred_scheduler] * len(predictor_params)
+    keep = [i for i, g in enumerate(groups) if g['params']]
+    optimizer = construct_optimizer(args, [groups[i] for i in keep])
+    scheduler = optim.lr_scheduler.LambdaLR(
+        optimizer, lr_lambda=[lambdas[i] for i in keep])
+    for _ in range(passed_steps):
+        scheduler.step()
+    return optimizer, scheduler
+
+
+class SyntheticLoader:
+    """Endless seeded batches in the reference's wire format
+    (utils/dataset.py:961-1020), rank-sharded by seed."""
+
+    def __init__(self, args, rank, steps):
+        self.args, self.rank, self.steps = args, rank, steps
+
+    def __iter__(self):
+        a = self.args
+        seq = a.prefix_length + a.suffix_length + 1
+        for i in range(self.steps):
+            yield synthetic.to_torch(synthetic.make_batch(
+                1234 + self.rank + 1000 * i, a.mbs, a.height, a.width,
+                a.synthetic_events, seq_len=seq))
+
+
+class _NullLogger:
+    def add_scalar(self, *a, **k):
+        pass
+
+
+def main(argv=None):
+    args = parse_args(sys.argv[1:] if argv is None else argv)
+    device = torch.device(args.device)
+    rank, local, world = parallel.init_distributed(device.type)
+    if device.type == 'cuda':
+        device = torch.device('cuda', local if world > 1 else
+                              (device.index or 0))
+        torch.cuda.set_device(device)
+    timers = EventTimer() if (args.timers and device.type == 'cuda') \
+        else FakeTimer()
+
+    model = init_model(args, device)
+    parallel.broadcast_parameters(model)
+    optimizer, scheduler = construct_train_tools(args, model)
+    losses = init_losses(args.shape, args.mbs, model, device,
+                         sequence_length=args.prefix_length +
+                         args.suffix_length + 1, timers=timers)
+    reducer = None
+    if world > 1 and hasattr(model, 'predictor'):
+        reducer = parallel.GradReducer()
+        model.predictor.reducer = reducer
+
+    logger = _NullLogger()
+    if rank == 0:
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            logger = SummaryWriter(str(args.log_path), max_queue=100000000,
+                                   flush_secs=100000000)
+        except Exception:       # tensorboard is not installed everywhere
+            pass
+
+    if args.synthetic:
+        loader = SyntheticLoader(args, rank,
+                                 args.training_steps * args.accum_step)
+    else:
+        try:    # dropped into the reference tree: use its data pipeline
+            from utils.dataloader import get_trainset_params, get_dataloader, \
+                choose_data_path
+            loader = get_dataloader(get_trainset_params(choose_data_path(args)))
+        except ImportError as e:
+            raise SystemExit(
+                'no dataset pipeline importable (the reference\'s utils.* and '
+                f'h5py are needed: {e}); pass --synthetic') from e
+
+    train(model, device, loader, optimizer, args.training_steps,
+          scheduler=scheduler, evaluator=losses, logger=logger,
+          weights=args.loss_weights, is_raw=args.is_raw,
+          accumulation_steps=args.accum_step, timers=timers, hooks={},
+          max_events_per_batch=args.max_events_per_batch, reducer=reducer)
+    if rank == 0:
+        torch.save({'model': model.state_dict(),
+                    'optimizer': optimizer.state_dict(),
+                    'global_step': args.training_steps},
+                   args.model / f'step_{args.training_steps}.pt')
+
+
+if __name__ == '__main__':
+    main()
