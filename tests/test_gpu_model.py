@@ -1,0 +1,181 @@
+"""End-to-end parity on the GPU: Model plugin contract, whole training step
+against the CPU port (oracle/), fused AdamW against torch.optim.AdamW,
+train loop, OpticalFlow wrapper."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from dvs_of_training_framework_amd import synthetic
+from oracle import cpu_oracle as orc
+from oracle.ref_model import ref_predictor
+
+pytestmark = pytest.mark.gpu
+GOLD = json.loads((Path(__file__).parent / 'golden' / 'plumbing.json').read_text())
+DEV = 'cuda'
+
+
+def make_model(depth=3, **kw):
+    from dvs_of_training_framework_amd.net import Model
+    torch.manual_seed(0)
+    return Model(torch.device(DEV), event_representation_depth=depth, **kw)
+
+
+def test_forward_contract_matches_dummynet_witness():
+    # config 1 shapes (DummyNet, B=4, 64x64): SURVEY App. B / plumbing.json
+    model = make_model(3)
+    batch = synthetic.to_torch(synthetic.make_batch(1234, 4, 64, 64), DEV)
+    with torch.no_grad():
+        flows, flow_ts, fsi, feats = model(batch['events'], batch['timestamps'],
+                                           batch['sample_idx'], (64, 64), raw=True,
+                                           intermediate=True)
+    g = GOLD['cfg1']
+    assert [list(f.shape) for f in flows] == g['shapes']
+    np.testing.assert_allclose(flow_ts.cpu().numpy(), g['flow_ts'], rtol=1e-6)
+    assert fsi.tolist() == g['flow_sample_idx'] and feats == ()
+    assert all(f.dtype == torch.float32 for f in flows)
+    assert hasattr(model, 'quantization_layer') and hasattr(model, 'predictor')
+    assert 'predictor.enc.0.conv.bias' in model.state_dict()
+
+
+def test_init_losses_probes_with_zero_events():
+    from dvs_of_training_framework_amd.loss import init_losses
+    ev = init_losses((32, 48), 2, make_model(5), DEV, sequence_length=1)
+    assert ev.shapes == [(4, 6), (8, 12), (16, 24), (32, 48)]
+
+
+def test_quantize_and_padding_paths():
+    model = make_model(5)
+    b_np = synthetic.make_batch(3, 2, 40, 56, 3000)       # not multiples of 16
+    b = synthetic.to_torch(b_np, DEV)
+    grid = model.quantize(b['events'], b['timestamps'], b['sample_idx'], (40, 56))
+    want, _, _ = orc.voxelize(b_np['events'], np.zeros(2, np.float32),
+                              np.full(2, 0.04, np.float32), 2, 5, 40, 56)
+    assert grid.shape == (2, 5, 40, 56)
+    np.testing.assert_allclose(grid.cpu().numpy(), want, atol=2e-5)
+    with torch.no_grad():
+        flows, _, _ = model(b['events'], b['timestamps'], b['sample_idx'], (40, 56))
+    assert [tuple(f.shape[2:]) for f in flows] == [(5, 7), (10, 14), (20, 28), (40, 56)]
+    # quantized input (raw=False) takes the same predictor path
+    with torch.no_grad():
+        flows2, _, _ = model(grid, b['timestamps'], b['sample_idx'], (40, 56), raw=False)
+    for a, c in zip(flows, flows2):
+        assert torch.allclose(a, c, atol=1e-6)
+
+
+@pytest.mark.parametrize('mish', [False, True])
+def test_training_step_vs_cpu_port(mish):
+    """voxelise -> predictor -> loss -> backward, HIP vs the CPU port: loss and
+    flows within 1e-3 relative, parameter gradients within 1e-3 (norm)."""
+    from dvs_of_training_framework_amd.loss import init_losses
+    from dvs_of_training_framework_amd.options import Mish
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch
+    B, H, W, C = 2, 32, 48, 5
+    model = make_model(C, activation=Mish() if mish else torch.nn.ReLU())
+    model.train()
+    ev = init_losses((H, W), B, model, DEV, sequence_length=1)
+    b_np = synthetic.make_batch(11, B, H, W, 1500)
+    batch = synthetic.to_torch(b_np, DEV)
+    loss, terms, tags, extra = process_minibatch(
+        model, batch, FakeTimer(), DEV, True, ev, [0.5, 1, 1], return_prediction=True)
+    loss.backward()
+    # CPU port
+    state = {k[len('predictor.'):]: v.detach().cpu().clone().requires_grad_(True)
+             for k, v in model.state_dict().items()}
+    grid, _, _ = orc.voxelize(b_np['events'], np.zeros(B, np.float32),
+                              np.full(B, 0.04, np.float32), B, C, H, W)
+    flows = ref_predictor(state, torch.from_numpy(grid), mish)
+    o_terms, o_loss, o_grads = orc.losses(
+        [f.detach().numpy() for f in flows], b_np['timestamps'].reshape(B, 2), np.arange(B),
+        b_np['images'], b_np['timestamps'], b_np['sample_idx'])
+    torch.autograd.backward(flows, [torch.from_numpy(g) for g in o_grads])
+    assert abs(float(loss.detach()) - o_loss) <= 1e-3 * abs(o_loss)
+    got_terms = np.array([list(t) for t in terms])
+    np.testing.assert_allclose(got_terms, o_terms, rtol=1e-3, atol=1e-6)
+    for f, r in zip(extra['prediction'], flows):
+        assert (f.detach().cpu() - r.detach()).abs().max() <= 1e-3 * r.abs().max() + 1e-6
+    for name, p in model.named_parameters():
+        r = state[name[len('predictor.'):]].grad
+        g = p.grad.detach().cpu()
+        assert (g - r).norm() <= 2e-3 * r.norm() + 1e-9, name
+    assert list(tags) == ['4x6', '8x12', '16x24', '32x48']
+
+
+def test_fused_adamw_matches_torch():
+    from dvs_of_training_framework_amd.optim import FusedAdamW
+    torch.manual_seed(3)
+    shapes = [(64, 5, 3, 3), (64,), (7,), (130, 33, 3, 3), (4097,)]
+    ps = [torch.randn(s) for s in shapes]
+    a = [p.clone().cuda().requires_grad_(True) for p in ps]
+    a[0] = a[0].detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = [p.clone().requires_grad_(True) for p in ps]
+    fo = FusedAdamW([{'params': a[:2], 'lr': 1e-2}, {'params': a[2:]}], lr=1e-3,
+                    weight_decay=1e-2, amsgrad=True)
+    to = torch.optim.AdamW([{'params': b[:2], 'lr': 1e-2}, {'params': b[2:]}], lr=1e-3,
+                           weight_decay=1e-2, amsgrad=True)
+    for step in range(4):
+        for x, y in zip(a, b):
+            g = torch.randn(y.shape) * (1 + step)
+            y.grad = g.clone()
+            x.grad = g.cuda().contiguous(memory_format=torch.channels_last) \
+                if x.dim() == 4 else g.cuda()
+            if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+                x.grad = g.cuda()
+        fo.step()
+        to.step()
+        for x, y in zip(a, b):
+            assert (x.detach().cpu() - y.detach()).abs().max() <= 2e-6 * y.abs().max()
+    sd = fo.state_dict()
+    assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'}
+
+
+def test_train_loop_reduces_loss_and_accumulates():
+    import train_flownet as tf
+    from dvs_of_training_framework_amd.loss import init_losses
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import train
+    args = tf.parse_args(['-m', '/tmp/dvsof_test_model', '--optimizer', 'ADAM', '-bs', '4',
+                          '-mbs', '2', '--height', '32', '--width', '32', '-lr', '1e-3',
+                          '--event-representation-depth', '3', '--synthetic',
+                          '--synthetic-events', '500', '-ne', '6', '-d', 'cuda:0'])
+    model = make_model(3)
+    optimizer, scheduler = tf.construct_train_tools(args, model)
+    assert type(optimizer).__name__ == 'FusedAdamW' and len(optimizer.param_groups) == 1
+    ev = init_losses(args.shape, args.mbs, model, DEV, sequence_length=1)
+
+    class Log:
+        rows = []
+
+        def add_scalar(self, t, v, x):
+            self.rows.append((t, v, x))
+    fixed = synthetic.make_batch(5, 2, 32, 32, 500)
+    loader = (synthetic.to_torch(fixed) for _ in range(100))
+    w0 = model.predictor.dec[3].flow.weight.detach().clone()
+    train(model, DEV, loader, optimizer, args.training_steps, scheduler, Log(), ev,
+          accumulation_steps=args.accum_step, timers=FakeTimer())
+    losses = [v for t, v, x in Log.rows if t == 'General/Train loss']
+    assert len(losses) == 6 and all(np.isfinite(losses))
+    assert losses[-1] < losses[0]
+    assert not torch.equal(w0, model.predictor.dec[3].flow.weight)
+    assert [x for t, v, x in Log.rows if t == 'General/Train loss'] == [4, 8, 12, 16, 20, 24]
+
+
+def test_optical_flow_wrapper(tmp_path):
+    # DummyNet/of.py:53-74,120-125 contract: NHWC numpy out
+    from dvs_of_training_framework_amd import OpticalFlow
+    model = make_model(9)
+    path = tmp_path / 'model.pth'
+    torch.save({'model': model.state_dict()}, path)
+    of = OpticalFlow((64, 80), model=str(path), device=torch.device(DEV))
+    rng = np.random.default_rng(0)
+    evs = [(rng.integers(0, 80, 300), rng.integers(0, 64, 300),
+            np.sort(rng.random(300)) * 0.05 + 10.0, rng.integers(0, 2, 300) * 2 - 1)
+           for _ in range(2)]
+    out = of(evs, [10.0, 10.0], [10.05, 10.05])
+    assert isinstance(out, np.ndarray) and out.shape == (2, 64, 80, 2)
+    allf = of(evs, [10.0, 10.0], [10.05, 10.05], return_all=True)
+    assert [a.shape for a in allf] == [(2, 8, 10, 2), (2, 16, 20, 2), (2, 32, 40, 2),
+                                       (2, 64, 80, 2)]

@@ -1,0 +1,209 @@
+"""CPU tests of the host-side mirror of the reference interface: flags,
+plugin loader, LR schedules, element selection, lazy term readback and the
+train loop's accumulate / step / hook / skip protocol."""
+import json
+import sys
+from argparse import ArgumentParser
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from dvs_of_training_framework_amd import options, synthetic
+from dvs_of_training_framework_amd.model import filter_kwargs, init_model
+from dvs_of_training_framework_amd.net import Model, get_local_idx
+from dvs_of_training_framework_amd.timer import FakeTimer
+from dvs_of_training_framework_amd import training
+
+GOLD = json.loads((Path(__file__).parent / 'golden' / 'plumbing.json').read_text())
+
+
+def test_get_local_idx_matches_reference():
+    # DummyNet/net.py:18-21 doc example, captured from the reference
+    li, sizes = get_local_idx(torch.tensor([0, 0, 1, 1, 2, 1, 2, 2, 2]))
+    assert li.tolist() == GOLD['get_local_idx']['local_idx']
+    assert sizes.tolist() == GOLD['get_local_idx']['shard_sizes']
+
+
+def test_flag_defaults_match_reference():
+    # utils/options.py:22-302 defaults
+    p = options.add_preprocessed_dataset_arguments(
+        options.add_train_arguments(ArgumentParser()))
+    a = p.parse_args(['-m', '/tmp/m'])
+    assert (a.bs, a.mbs, a.lr, a.wdw, a.optimizer) == (32, 32, 1e-3, 1e-4, 'RANGER')
+    assert (a.height, a.width, a.event_representation_depth, a.cl) == (256, 256, 9, 6)
+    assert (a.half_life, a.training_steps, a.num_warmup_steps, a.vp) == (100000, 1000000, 0, 1000)
+    assert a.loss_weights == [0.5, 1, 1] and a.rs == 0.5
+    assert (a.num_checkpoints, a.permanent_interval, a.checkpointing_interval) == (2, 10000, 1000)
+    assert a.max_events_per_batch == 35000000 and str(a.flownet_path) == 'EV_FlowNet'
+    a = p.parse_args(['-m', '/tmp/m', '-bs', '8', '-mbs', '4'])
+    a = options.validate_train_args(a)
+    assert a.accum_step == 2 and a.shape == (256, 256) and a.is_raw
+    with pytest.raises(AssertionError):
+        options.validate_train_args(p.parse_args(['-m', '/tmp/m', '-bs', '8', '-mbs', '3']))
+
+
+def test_model_kwargs_and_filter():
+    a = SimpleNamespace(prefix_length=1, suffix_length=2, max_sequence_length=4,
+                        dynamic_sample_length=False, event_representation_depth=5,
+                        mish=True)
+    kw = options.options2model_kwargs(a)
+    assert type(kw['activation']).__name__ == 'Mish' and kw['event_representation_depth'] == 5
+
+    def ctor(device, prefix_length=0, suffix_length=0):
+        pass
+    assert filter_kwargs(ctor, kw) == {'prefix_length': 1, 'suffix_length': 2}
+    assert filter_kwargs(lambda device, **k: 0, kw) == kw
+
+
+def test_init_model_imports_plugin_by_package_name():
+    # utils/model.py:35-47: <flownet_path.name>.net found on sys.path
+    sys.path.insert(0, str(Path(__file__).parent))
+    try:
+        a = SimpleNamespace(flownet_path=Path('anything/fake_flownet'), sp=None, mish=False,
+                            prefix_length=0, suffix_length=0, max_sequence_length=1,
+                            dynamic_sample_length=False, event_representation_depth=9)
+        m = init_model(a, torch.device('cpu'))
+        assert type(m).__module__ == 'fake_flownet.net'
+        # like the reference's find_spec: a missing package is a
+        # ModuleNotFoundError, a package without net.py fails the assertion
+        with pytest.raises(ModuleNotFoundError):
+            a.flownet_path = Path('no_such_pkg')
+            init_model(a, torch.device('cpu'))
+        with pytest.raises(AssertionError):
+            a.flownet_path = Path('golden')      # tests/golden has no net.py
+            (Path(__file__).parent / 'golden' / '__init__.py').touch()
+            try:
+                init_model(a, torch.device('cpu'))
+            finally:
+                (Path(__file__).parent / 'golden' / '__init__.py').unlink()
+    finally:
+        sys.path.pop(0)
+
+
+def test_lr_schedule_matches_reference_sequence():
+    import train_flownet as tf
+    g = GOLD['lr_schedule']
+    a = SimpleNamespace(training_steps=g['args']['steps'], rs=g['args']['rs'],
+                        num_warmup_steps=g['args']['warmup'], half_life=g['args']['half_life'])
+    pred, rep = tf.make_schedulers(a)
+    p = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+    opt = torch.optim.SGD([{'params': [p[0]]}, {'params': [p[1]]}], lr=1.0)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=[rep, pred])
+    seq = []
+    for _ in range(g['args']['n']):
+        seq.append([x['lr'] for x in opt.param_groups])
+        opt.step()
+        sch.step()
+    np.testing.assert_allclose(seq, g['lrs'], rtol=1e-12)
+
+
+def test_element_selection_matches_dummynet():
+    # DummyNet/net.py:70-78 with prefix = suffix = 1 (captured from the reference)
+    m = Model('cpu', prefix_length=1, suffix_length=1, max_sequence_length=3,
+              event_representation_depth=3)
+    ts = torch.arange(8, dtype=torch.float32) * 0.04
+    si = torch.tensor([0, 0, 0, 0, 1, 1, 1, 1])
+    for strict in (True, False):
+        m.strict = strict
+        start, stop, t0, t1 = m._select(ts, si, 2)
+        flow_ts = torch.stack([ts[start], ts[stop]], 1)
+        np.testing.assert_allclose(flow_ts.numpy(), GOLD['prefix1_suffix1']['flow_ts'], rtol=1e-6)
+        assert si[start].tolist() == GOLD['prefix1_suffix1']['flow_sample_idx']
+        assert t0.tolist() == [0.0, pytest.approx(0.16)] and t1.tolist() == \
+            [pytest.approx(0.12), pytest.approx(0.28)]
+    m.strict = True
+    with pytest.raises(AssertionError):
+        m._select(ts[:7], si[:7], 2)
+    # interleaved (unsorted) sample ids go through the general path
+    si2 = torch.tensor([0, 1, 0, 1, 0, 1, 0, 1])
+    start, stop, _, _ = m._select(ts, si2, 2)
+    assert start.tolist() == [2, 3] and stop.tolist() == [4, 5]
+
+
+def test_synthetic_batch_wire_format():
+    # collate_wrapper contract, utils/dataset.py:961-1020 / test_dataset.py:260-297
+    b = synthetic.to_torch(synthetic.make_batch(1, 3, 16, 32, 100))
+    ev = b['events']
+    for k in ('x', 'y', 'polarity', 'element_index', 'sample_index'):
+        assert ev[k].dtype == torch.long and ev[k].shape == (300,)
+    assert ev['timestamp'].dtype == torch.float32
+    assert set(ev['polarity'].tolist()) <= {-1, 1}
+    assert b['timestamps'].tolist() == pytest.approx([0, 0.04] * 3)
+    assert b['sample_idx'].tolist() == [0, 0, 1, 1, 2, 2]
+    assert b['images'].shape == (6, 1, 16, 32) and b['images'].dtype == torch.float32
+    assert b['size'] == 3
+    t = ev['timestamp'].view(3, 100)
+    assert bool((t[:, 1:] >= t[:, :-1]).all())
+
+
+class _Evaluator:
+    """CPU stand-in with the Losses call signature."""
+    def __call__(self, flows, flow_ts, fsi, images, ts, si):
+        return (tuple(f.mean() for f in flows), tuple(2 * f.mean() for f in flows),
+                tuple(0 * f.mean() for f in flows))
+
+
+class _Logger:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, v, x):
+        self.rows.append((tag, float(v), x))
+
+
+def _loader(n, B=2, events=10):
+    for i in range(n):
+        yield synthetic.to_torch(synthetic.make_batch(i, B, 16, 16, events))
+
+
+def test_combined_loss_and_lazy_terms():
+    flows = [torch.full((1, 2, 2, 2), 2.0, requires_grad=True) for _ in range(4)]
+    loss, terms = training.combined_loss(_Evaluator(), flows, None, None, None, None, None,
+                                         None, weights=[0.5, 1, 1])
+    assert float(loss) == pytest.approx(0.5 * 2 + 1 * 4)         # utils/training.py:23
+    vals = [list(t) for t in training._lazy_items(terms)]
+    assert vals == [[2.0] * 4, [4.0] * 4, [0.0] * 4]
+
+
+def test_train_loop_protocol():
+    sys.path.insert(0, str(Path(__file__).parent))
+    from fake_flownet.net import Model as Fake
+    sys.path.pop(0)
+    model = Fake('cpu')
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    log, calls = _Logger(), []
+    training.train(model, 'cpu', _loader(10), opt, num_steps=3, scheduler=sch, logger=log,
+                   evaluator=_Evaluator(), accumulation_steps=2, timers=FakeTimer(),
+                   hooks={'h': lambda step, sp: calls.append((step, sp))},
+                   max_events_per_batch=10 ** 6)
+    # 3 optimizer steps of 2 micro-batches of 2 samples (utils/training.py:151-167)
+    assert calls == [(1, 4), (2, 8), (3, 12)]
+    # d loss/d scale = 0.5*1 + 1*2 per micro batch, /2 each, two of them
+    assert float(model.scale) == pytest.approx(1 - 0.1 * 2.5 * 3, rel=1e-5)
+    tags = {r[0] for r in log.rows}
+    assert 'General/Train loss' in tags and 'Train/photometric loss/16x16' in tags
+    assert 'General/learning rate/0' in tags and 'Train/out regularization/2x2' in tags
+    first = [r for r in log.rows if r[0] == 'General/Train loss'][0]
+    assert first[2] == 4 and first[1] == pytest.approx(2.5)   # x axis = samples_passed
+    # oversize batches are skipped, not counted (utils/training.py:141-150)
+    calls.clear()
+    training.train(model, 'cpu', _loader(4, events=50), opt, num_steps=2, scheduler=sch,
+                   logger=log, evaluator=_Evaluator(), timers=FakeTimer(),
+                   hooks={'h': lambda step, sp: calls.append(step)},
+                   max_events_per_batch=60)
+    assert calls == []
+
+
+def test_validate_loop_tags():
+    sys.path.insert(0, str(Path(__file__).parent))
+    from fake_flownet.net import Model as Fake
+    sys.path.pop(0)
+    log = _Logger()
+    training.validate(Fake('cpu'), 'cpu', list(_loader(2)), 7, log, _Evaluator())
+    assert ('General/Validation loss', pytest.approx(2.5), 7) in \
+        [(t, v, x) for t, v, x in log.rows]
+    assert any(t == 'Validation/smoothness loss/16x16' for t, _, _ in log.rows)
