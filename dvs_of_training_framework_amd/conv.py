@@ -49,6 +49,9 @@ _lib.register('dvsof_flow_head_bwd', _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp,
                                           _vp])
 _lib.register('dvsof_act_bwd', _i, [_vp, _vp, _i, _vp, _sz, _vp])
 _lib.register('dvsof_conv2d_tile_id', _i, [_P(ConvDesc), _i])
+_lib.register('dvsof_conv2d_fwd_weight_elems', _sz, [_P(ConvDesc)])
+_lib.register('dvsof_conv2d_dgrad_weight_elems', _sz, [_P(ConvDesc)])
+_lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])
 
 
 def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
@@ -89,6 +92,26 @@ def conv_fwd(desc, weight, bias, device, residual=None, want_z=False):
         _lib.ptr(residual), y.data_ptr(), _lib.ptr(z), _lib.stream()),
         'dvsof_conv2d_fwd')
     return y, z
+
+
+def prepare(desc, weight, want_dgrad):
+    """-> (w_fwd, w_dgrad): prepared weights (dvsof_conv2d_prepare).  w_fwd is
+    the raw weight itself unless the layer runs as sub-pixel phases."""
+    lib = _lib.lib()
+    raw = desc.Cout * desc.ksize ** 2 * sum(desc.src[i].C
+                                            for i in range(desc.nsrc))
+    nf = lib.dvsof_conv2d_fwd_weight_elems(ctypes.byref(desc))
+    w_fwd = weight if nf == raw else torch.empty(
+        nf, dtype=torch.float32, device=weight.device)
+    w_dg = torch.empty(lib.dvsof_conv2d_dgrad_weight_elems(ctypes.byref(desc)),
+                       dtype=torch.float32, device=weight.device) \
+        if want_dgrad else None
+    if nf != raw or want_dgrad:
+        _lib.check(lib.dvsof_conv2d_prepare(
+            ctypes.byref(desc), weight.data_ptr(),
+            None if nf == raw else w_fwd.data_ptr(), _lib.ptr(w_dg),
+            _lib.stream()), 'dvsof_conv2d_prepare')
+    return w_fwd, w_dg
 
 
 def flip_transpose(weight, Cout, ksize, Ctot):

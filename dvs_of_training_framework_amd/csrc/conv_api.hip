@@ -54,6 +54,70 @@ bool desc_ok(const dvsof_conv_desc_t *d, int &Ctot, int &Ho, int &Wo)
     return true;
 }
 
+bool is_subpixel(const dvsof_conv_desc_t *d)
+{   // up2 + 3x3/pad1/stride1 == four 2x2 phase convolutions on the low-res input
+    return d->upsample && d->ksize == 3 && d->pad == 1 && d->stride == 1;
+}
+
+// Wf[ph][co][a][b][ci] = sum_{ky in S(py,a)} sum_{kx in S(px,b)} W[co][ky][kx][ci]
+// S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2}; ph = 2*py + px.
+__global__ __launch_bounds__(256) void subpixel_fwd_weights_kernel(const float *__restrict__ w,
+                                                                   float *__restrict__ wf, int Cout,
+                                                                   int Ctot)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Cout * Ctot) return;
+    const int ci = (int)(i % Ctot), co = (int)(i / Ctot);
+    float k[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t / 3][t % 3] = w[((size_t)co * 9 + t) * Ctot + ci];
+    // row/column partial sums for (p, a): {0},{1,2},{0,1},{2}
+    float r[4][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        r[0][x] = k[0][x];
+        r[1][x] = k[1][x] + k[2][x];
+        r[2][x] = k[0][x] + k[1][x];
+        r[3][x] = k[2][x];
+    }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float *rr = r[2 * py + a];
+                    const int q = 2 * px + b;
+                    const float v = q == 0 ? rr[0] : q == 1 ? rr[1] + rr[2] : q == 2 ? rr[0] + rr[1] : rr[2];
+                    wf[((((size_t)(2 * py + px) * Cout + co) * 2 + a) * 2 + b) * Ctot + ci] = v;
+                }
+}
+
+// Wd[ci][ty][tx][co] = Wf[ph][co][a][b][ci], ty -> (py,a): 0->(1,1) 1->(0,1) 2->(1,0) 3->(0,0)
+__global__ __launch_bounds__(256) void subpixel_dgrad_weights_kernel(const float *__restrict__ wf,
+                                                                     float *__restrict__ wd,
+                                                                     int Cout, int Ctot)
+{
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, ty = z >> 2, tx = z & 3;
+    const int py = (ty == 0 || ty == 2) ? 1 : 0, a = ty < 2 ? 1 : 0;
+    const int px = (tx == 0 || tx == 2) ? 1 : 0, b = tx < 2 ? 1 : 0;
+    const float *in = wf + ((size_t)(2 * py + px) * Cout * 4 + (a * 2 + b)) * Ctot;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + lx;
+        tile[r][lx] = (co < Cout && ci < Ctot) ? in[(size_t)co * 4 * Ctot + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + lx;
+        if (ci < Ctot && co < Cout) wd[((size_t)ci * 16 + z) * Cout + co] = tile[lx][r];
+    }
+}
+
 __global__ __launch_bounds__(256) void flip_transpose_kernel(const float *__restrict__ w,
                                                              float *__restrict__ wt, int Cout,
                                                              int taps, int Ctot)
@@ -234,6 +298,28 @@ void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParam
     P.Cin_tot = Ctot;
     P.M = d->B * Ho * Wo;
     P.klen = 0;
+    P.nph = 1;
+    P.ph_pad = 0;
+    P.S = 1;
+    P.g_sb = (long long)Ho * Wo * d->Cout;
+    P.g_sy = Wo * d->Cout;
+    P.g_sx = d->Cout;
+    P.g_py = P.g_px = 0;
+    if (is_subpixel(d)) {   // four 2x2 phase problems over the low-res pixels
+        P.Hv = d->H;
+        P.Wv = d->W;
+        P.up = UP_NONE;
+        P.Ho = d->H;
+        P.Wo = d->W;
+        P.ks = 2;
+        P.M = d->B * d->H * d->W;
+        P.nph = 4;
+        P.ph_pad = 1;
+        P.g_sy = 2 * Wo * d->Cout;
+        P.g_sx = 2 * d->Cout;
+        P.g_py = Wo * d->Cout;
+        P.g_px = d->Cout;
+    }
     P.gout = nullptr;
     P.dW = nullptr;
     P.dbias = nullptr;
@@ -242,6 +328,9 @@ void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParam
 }  // namespace
 
 extern "C" {
+
+int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize, int Ctot,
+                                void *stream);
 
 int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const float *bias,
                      const float *residual, float *y, float *z, void *stream)
@@ -253,7 +342,7 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     for (int i = 0; i < d->nsrc; ++i)
         P.src[i] = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
     P.ndst = 1;
-    P.dst[0] = {y, residual, nullptr, nullptr, (long long)Ho * Wo * d->Cout, Wo * d->Cout, d->Cout, 1, d->Cout};
+    P.dst[0] = {y, residual, nullptr, nullptr, (long long)Ho * Wo * d->Cout, Wo * d->Cout, d->Cout, 1, d->Cout, 0, 0};
     P.W = weight;
     P.bias = bias;
     P.zout = z;
@@ -273,6 +362,25 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     P.quad = 0;
     P.act = d->act;
     P.bwd_act = ACT_NONE;
+    P.nph = 1;
+    P.ph_pad = 0;
+    P.w_phase_stride = 0;
+    if (is_subpixel(d)) {   // `weight` is the prepared Wf[4][Cout][2][2][Ctot]
+        P.up = UP_NONE;
+        P.Hv = d->H;
+        P.Wv = d->W;
+        P.Ho = d->H;
+        P.Wo = d->W;
+        P.ks = 2;
+        P.M = d->B * d->H * d->W;
+        P.nph = 4;
+        P.ph_pad = 1;
+        P.w_phase_stride = (long long)d->Cout * 4 * Ctot;
+        P.dst[0].sy = 2 * Wo * d->Cout;
+        P.dst[0].sx = 2 * d->Cout;
+        P.dst[0].ph_y = Wo * d->Cout;
+        P.dst[0].ph_x = d->Cout;
+    }
     return gconv_launch(P, 0, as_stream(stream));
 }
 
@@ -288,7 +396,7 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
     for (int i = 0; i < d->nsrc; ++i) {
         if (!dst[i].p) return DVSOF_EINVAL;
         const GSrc g = make_src(nullptr, d->src[i].C, d->src[i].layout, d->H, d->W);
-        P.dst[i] = {dst[i].p, dst[i].addend, dst[i].addend2, dst[i].actsrc, g.sb, g.sy, g.sx, g.sc, g.C};
+        P.dst[i] = {dst[i].p, dst[i].addend, dst[i].addend2, dst[i].actsrc, g.sb, g.sy, g.sx, g.sc, g.C, 0, 0};
     }
     P.W = weight_t;
     P.bias = nullptr;
@@ -301,7 +409,22 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
     P.Cin_tot = d->Cout;
     P.act = ACT_NONE;
     P.bwd_act = bwd_act;
-    if (d->upsample) {  // rows = upsampled pixels, quad-summed to H x W
+    P.nph = 1;
+    P.ph_pad = 0;
+    P.w_phase_stride = 0;
+    if (is_subpixel(d)) {
+        // transpose of (up2 + 3x3) = 4x4 stride-2 convolution of gout with
+        // the prepared Wd[Ctot][4][4][Cout]; rows = low-res input pixels
+        P.up = UP_NONE;
+        P.Hv = Ho;
+        P.Wv = Wo;
+        P.Ho = d->H;
+        P.Wo = d->W;
+        P.quad = 0;
+        P.ks = 4;
+        P.stride = 2;
+        P.pad = 1;
+    } else if (d->upsample) {  // rows = upsampled pixels, quad-summed to H x W
         P.up = UP_NONE;
         P.Hv = Ho;
         P.Wv = Wo;
@@ -348,13 +471,52 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
     return wgrad_launch(P, dweight, dbias, (float *)ws, ws_bytes / sizeof(float), as_stream(stream));
 }
 
+size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *d)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
+    return (size_t)d->Cout * Ctot * (is_subpixel(d) ? 16 : d->ksize * d->ksize);
+}
+
+size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *d)
+{
+    return dvsof_conv2d_fwd_weight_elems(d);
+}
+
+int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float *w_fwd,
+                         float *w_dgrad, void *stream)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo) || !weight) return DVSOF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (is_subpixel(d)) {
+        if (!w_fwd) return DVSOF_EINVAL;
+        const size_t n = (size_t)d->Cout * Ctot;
+        hipLaunchKernelGGL(subpixel_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                           0, st, weight, w_fwd, d->Cout, Ctot);
+        DVSOF_LAUNCH_CHECK();
+        if (w_dgrad) {
+            dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);
+            hipLaunchKernelGGL(subpixel_dgrad_weights_kernel, grid, dim3(256), 0, st,
+                               (const float *)w_fwd, w_dgrad, d->Cout, Ctot);
+            DVSOF_LAUNCH_CHECK();
+        }
+        return DVSOF_OK;
+    }
+    if (w_fwd && w_fwd != weight)
+        DVSOF_HIP_TRY(hipMemcpyAsync(w_fwd, weight, dvsof_conv2d_fwd_weight_elems(d) * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
+    if (w_dgrad) return dvsof_weight_flip_transpose(weight, w_dgrad, d->Cout, d->ksize, Ctot, stream);
+    return DVSOF_OK;
+}
+
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return DVSOF_EINVAL;
     if (kind == 0) return gconv_pick_tile((long long)d->B * Ho * Wo, d->Cout);
     if (kind == 1) {
-        const int up = d->upsample ? 2 : 1;
+        const int up = (d->upsample && !is_subpixel(d)) ? 2 : 1;
         return gconv_pick_tile((long long)d->B * d->H * up * d->W * up, Ctot);
     }
     if (kind == 2) {

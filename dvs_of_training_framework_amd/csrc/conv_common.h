@@ -35,6 +35,7 @@ struct GDst {
     long long sb;
     int sy, sx, sc;
     int C;
+    int ph_y, ph_x;       // element offsets of output phase (py, px)
 };
 
 struct GConvParams {
@@ -48,6 +49,9 @@ struct GConvParams {
     int up;             // UP_*
     int Ho, Wo;         // GEMM row grid
     int stride, pad, ks;
+    int nph;            // 1, or 4 sub-pixel output phases (blockIdx.z)
+    int ph_pad;         // pad of phase (py,px) = pad - py*ph_pad / pad - px*ph_pad
+    long long w_phase_stride;  // elements between the weights of two phases
     int N, Cin_tot, M;
     int quad;           // rows ordered (b,y,x,dy,dx); epilogue sums the 2x2 quad
     int act;            // forward activation (ACT_*), applied after bias+addend
@@ -65,6 +69,10 @@ struct WGradParams {
     int Cout, Cin_tot, M;
     int klen;             // pixels per K split (multiple of BK)
     int tile_begin[4];    // first column tile of each source; [nsrc] = total
+    long long g_sb;       // gout strides (elements): batch, row, pixel
+    int g_sy, g_sx;
+    int g_py, g_px;       // gout offsets of output phase (py, px)
+    int nph, ph_pad, S;   // phases (1|4), pad shift per phase, K splits
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act)

@@ -74,6 +74,9 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int taps = P.ks * P.ks;
+    const int ph = blockIdx.z, phy = ph >> 1, phx = ph & 1;
+    const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
+    const float *Wp = P.W + (size_t)ph * P.w_phase_stride;
 
     for (int r = tid; r < BM; r += CONV_NT) {
         const int m = m0 + r;
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
                 oy = 2 * (t % hq) + (j >> 1);
                 b = t / hq;
             }
-            y = oy * P.stride - P.pad;
-            x = ox * P.stride - P.pad;
+            y = oy * P.stride - pad_y;
+            x = ox * P.stride - pad_x;
         }
         rowB[r] = b;
         rowY[r] = y;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
                 const int n = n0 + r;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if ((BN >= 64 || r < BN) && cok && n < P.N)
-                    v = *(const f32x4u *)(P.W + (size_t)n * wrow + (size_t)it.tap * P.Cin_tot +
+                    v = *(const f32x4u *)(Wp + (size_t)n * wrow + (size_t)it.tap * P.Cin_tot +
                                           it.coff + c);
                 rb[4 * i + 0] = v[0]; rb[4 * i + 1] = v[1];
                 rb[4 * i + 2] = v[2]; rb[4 * i + 3] = v[3];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
             for (int i = 0; i < BN / 16; ++i) {
                 const int n = n0 + (tid >> 4) + 16 * i;
                 rb[i] = (fok && n < P.N)
-                            ? P.W[(size_t)n * wrow + (size_t)tap * P.Cin_tot + it.coff + c]
+                            ? Wp[(size_t)n * wrow + (size_t)tap * P.Cin_tot + it.coff + c]
                             : 0.f;
             }
         }
@@ -261,9 +264,10 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = rbase + (reg & 3) + 8 * (reg >> 2);
                     if (m0 + row >= P.M) continue;
-                    const int oy = (rowY[row] + P.pad) >> sshift, ox = (rowX[row] + P.pad) >> sshift;
+                    const int oy = (rowY[row] + pad_y) >> sshift, ox = (rowX[row] + pad_x) >> sshift;
                     const size_t o = (size_t)rowB[row] * D.sb + (size_t)oy * D.sy +
-                                     (size_t)ox * D.sx + (size_t)c * D.sc;
+                                     (size_t)ox * D.sx + (size_t)c * D.sc + phy * D.ph_y +
+                                     phx * D.ph_x;
                     float v = acc[tm][tn][reg] + bias;
                     if (D.addend) v += D.addend[o];
                     if (D.addend2) v += D.addend2[o];
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
                 for (int g = 0; g < 4; ++g) {
                     const int row = rbase + 8 * g;
                     if (m0 + row >= P.M) continue;
-                    const int y = (rowY[row] + P.pad) >> 1, x = (rowX[row] + P.pad) >> 1;
+                    const int y = (rowY[row] + pad_y) >> 1, x = (rowX[row] + pad_x) >> 1;
                     const size_t o = (size_t)rowB[row] * D.sb + (size_t)y * D.sy +
                                      (size_t)x * D.sx + (size_t)c * D.sc;
                     float v = (acc[tm][tn][4 * g] + acc[tm][tn][4 * g + 1]) +
@@ -304,7 +308,7 @@ template <int WROWS, int WCOLS, int TM, int TN>
 int launch(const GConvParams &P, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
-    dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN);
+    dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN, P.nph);
     hipLaunchKernelGGL((gconv_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), 0, st, P,
                        count_steps(P));
     DVSOF_LAUNCH_CHECK();
@@ -316,11 +320,26 @@ int launch(const GConvParams &P, hipStream_t st)
 // largest tile that still gives every CU work (256 CUs)
 int gconv_pick_tile(long long m, long long n)
 {
-    auto blocks = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn); };
-    if (n <= 32) return blocks(256, 32) >= 512 ? 4 : 5;
-    if (n >= 128 && blocks(128, 128) >= 512) return 1;
-    if (blocks(128, 64) >= 512) return 2;
-    return 3;
+    // candidates: id, BM, BN.  Cost = padded MACs, with a penalty for grids
+    // that cannot fill 256 CUs and a mild preference for larger tiles.
+    static const int cand[5][3] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {4, 256, 32}, {5, 128, 32}};
+    int best = 3;
+    double best_cost = 1e300;
+    for (int i = 0; i < 5; ++i) {
+        const int bm = cand[i][1], bn = cand[i][2];
+        const long long tm = (m + bm - 1) / bm, tn = (n + bn - 1) / bn;
+        const long long blocks = tm * tn;
+        double cost = (double)tm * bm * (double)tn * bn;
+        const long long waves = (blocks + 255) / 256;          // rounds of 256 CUs
+        cost *= (double)(waves * 256) / (double)blocks;        // tail/under-fill
+        if (bn == 32) cost *= 1.25;                            // low operand reuse
+        else if (bm * bn == 64 * 64) cost *= 1.10;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = cand[i][0];
+        }
+    }
+    return best;
 }
 
 // Internal entry (not part of the C ABI): picks the tile shape and launches.
@@ -330,9 +349,10 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
         return DVSOF_EINVAL;
     if (P.quad && ((P.Ho | P.Wo) & 1)) return DVSOF_EINVAL;
     if (P.stride != 1 && P.stride != 2) return DVSOF_EINVAL;
+    if (P.nph != 1 && P.nph != 4) return DVSOF_EINVAL;
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
-    const int tile = tile_hint > 0 ? tile_hint : gconv_pick_tile(P.M, P.N);
+    const int tile = tile_hint > 0 ? tile_hint : gconv_pick_tile((long long)P.M * P.nph, P.N);
     switch (tile) {
     case 1: return launch<2, 2, 2, 2>(P, st);  // 128 x 128
     case 2: return launch<2, 2, 2, 1>(P, st);  // 128 x 64

@@ -46,7 +46,11 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_kernel(const WGradParams P)
     const int f0 = ((int)blockIdx.x - P.tile_begin[s]) * BN;
     const int fmax = taps * S.C;
     const int co0 = blockIdx.y * BMc;
-    const int kbeg = blockIdx.z * P.klen;
+    const int ph = blockIdx.z / P.S, split = blockIdx.z - ph * P.S;
+    const int phy = ph >> 1, phx = ph & 1;
+    const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
+    const size_t g_ph = (size_t)phy * P.g_py + (size_t)phx * P.g_px;
+    const int kbeg = split * P.klen;
     const int kend = min(P.M, kbeg + P.klen);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
     const bool flat = S.flat != 0;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_kernel(const WGradParams P)
         if (!ok) return;
         const int ox = pix % P.Wo, t = pix / P.Wo;
         const int oy = t % P.Ho, b = t / P.Ho;
-        const int Y = oy * P.stride - P.pad + kyB, X = ox * P.stride - P.pad + kxB;
+        const int Y = oy * P.stride - pad_y + kyB, X = ox * P.stride - pad_x + kxB;
         ok = ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
         if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
         const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
@@ -84,8 +88,12 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_kernel(const WGradParams P)
         for (int i = 0; i < PA; ++i) {
             const int r = pra + RPA * i, pix = kbase + r;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < BK && a_ok && pix < kend)
-                v = *(const f32x4u *)(P.gout + (size_t)pix * P.Cout + co0 + 4 * qa);
+            if (r < BK && a_ok && pix < kend) {
+                const int ox = pix % P.Wo, t = pix / P.Wo;
+                const int oy = t % P.Ho, b = t / P.Ho;
+                v = *(const f32x4u *)(P.gout + (size_t)b * P.g_sb + (size_t)oy * P.g_sy +
+                                      (size_t)ox * P.g_sx + g_ph + co0 + 4 * qa);
+            }
             rga[i] = v;
         }
         if (!flat) {
@@ -217,8 +225,38 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     }
 }
 
+// Sub-pixel fold: the 3x3 weight gradient from the 4 phases' 2x2 gradients,
+//   dW[co][ky][kx][ci] = sum over (py,a) with ky in S(py,a), (px,b) with kx in S(px,b),
+//   S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2}   (and over the K splits).
+// slab[(ph*S + s)][co][a][b][ci], ph = 2*py + px.
+__global__ __launch_bounds__(256) void subpixel_fold_kernel(const float *__restrict__ slab,
+                                                            float *__restrict__ dW, int Cout,
+                                                            int Ctot, int S)
+{
+    const size_t n = (size_t)Cout * 9 * Ctot;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int ci = (int)(i % Ctot);
+    const int tap = (int)((i / Ctot) % 9), co = (int)(i / ((size_t)9 * Ctot));
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    // contributors (phase bit, tap bit) per kernel row/column index
+    const int pa[3][2][2] = {{{0, 0}, {1, 0}}, {{0, 1}, {1, 0}}, {{0, 1}, {1, 1}}};
+    const size_t wsize = (size_t)Cout * 4 * Ctot;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int py = pa[ky][u][0], a = pa[ky][u][1], px = pa[kx][v][0], b = pa[kx][v][1];
+            const size_t off = ((size_t)co * 4 + a * 2 + b) * Ctot + ci;
+            const float *sl = slab + (size_t)(2 * py + px) * S * wsize + off;
+            for (int z = 0; z < S; ++z) acc += sl[(size_t)z * wsize];
+        }
+    dW[i] = acc;
+}
+
 template <int WROWS, int WCOLS, int TM, int TN>
-int launch(WGradParams &P, int S, hipStream_t st)
+int launch(WGradParams &P, hipStream_t st)
 {
     constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
     const int taps = P.ks * P.ks;
@@ -228,7 +266,7 @@ int launch(WGradParams &P, int S, hipStream_t st)
         t += (taps * P.src[s].C + BN - 1) / BN;
     }
     P.tile_begin[P.nsrc] = t;
-    dim3 grid(t, (P.Cout + BMc - 1) / BMc, S);
+    dim3 grid(t, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
     hipLaunchKernelGGL((wgrad_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
@@ -264,6 +302,7 @@ int wgrad_splits(const WGradParams &P0, int *tile_out)
     long long tiles = 0;
     for (int s = 0; s < P0.nsrc; ++s) tiles += (taps * P0.src[s].C + bn - 1) / bn;
     tiles *= (P0.Cout + bm - 1) / bm;
+    tiles *= P0.nph;
     // aim at >= 1024 workgroups, at least 8 K slices (128 pixels) per split
     int S = (int)((1024 + tiles - 1) / tiles);
     const int maxS = (P0.M + 127) / 128;
@@ -274,36 +313,46 @@ int wgrad_splits(const WGradParams &P0, int *tile_out)
     return S;
 }
 
-// Internal entry: dW_ws/dbias_ws hold S slabs when S > 1, results go to dW/dbias.
+// Internal entry: ws holds the nph*S slabs when needed, results go to dW/dbias.
+// In phase mode (nph = 4) dW is the folded [Cout][3][3][Cin_tot] gradient.
 int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats, hipStream_t st)
 {
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
     int tile;
     const int S = wgrad_splits(P, &tile);
+    P.S = S;
+    const int nslab = S * P.nph;
     const size_t wsize = (size_t)P.Cout * P.ks * P.ks * P.Cin_tot;
-    const size_t need = S > 1 ? (size_t)S * (wsize + (dbias ? P.Cout : 0)) : 0;
+    const bool direct = nslab == 1;
+    const size_t need = direct ? 0 : (size_t)nslab * (wsize + (dbias ? P.Cout : 0));
     if (need > ws_floats) return DVSOF_ENOSPACE;
     P.klen = (((P.M + S - 1) / S) + BK - 1) / BK * BK;
-    P.dW = S > 1 ? ws : dW;
-    P.dbias = dbias ? (S > 1 ? ws + (size_t)S * wsize : dbias) : nullptr;
+    P.dW = direct ? dW : ws;
+    P.dbias = dbias ? (direct ? dbias : ws + (size_t)nslab * wsize) : nullptr;
     int rc;
     switch (tile) {
-    case 1: rc = launch<2, 2, 2, 2>(P, S, st); break;
-    case 2: rc = launch<2, 2, 2, 1>(P, S, st); break;
-    case 3: rc = launch<2, 2, 1, 1>(P, S, st); break;
-    case 4: rc = launch<2, 2, 1, 2>(P, S, st); break;
-    default: rc = launch<1, 4, 1, 1>(P, S, st); break;
+    case 1: rc = launch<2, 2, 2, 2>(P, st); break;
+    case 2: rc = launch<2, 2, 2, 1>(P, st); break;
+    case 3: rc = launch<2, 2, 1, 1>(P, st); break;
+    case 4: rc = launch<2, 2, 1, 2>(P, st); break;
+    default: rc = launch<1, 4, 1, 1>(P, st); break;
     }
     if (rc) return rc;
-    if (S > 1) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wsize + 1023) / 1024)), dim3(256), 0,
-                           st, (const float *)ws, dW, wsize, S);
+    if (!direct) {
+        if (P.nph == 4) {
+            const size_t n = (size_t)P.Cout * 9 * P.Cin_tot;
+            hipLaunchKernelGGL(subpixel_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                               st, (const float *)ws, dW, P.Cout, P.Cin_tot, S);
+        } else {
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wsize + 1023) / 1024)),
+                               dim3(256), 0, st, (const float *)ws, dW, wsize, S);
+        }
         DVSOF_LAUNCH_CHECK();
         if (dbias) {
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((P.Cout + 1023) / 1024)),
-                               dim3(256), 0, st, (const float *)(ws + (size_t)S * wsize), dbias,
-                               (size_t)P.Cout, S);
+                               dim3(256), 0, st, (const float *)(ws + (size_t)nslab * wsize), dbias,
+                               (size_t)P.Cout, nslab);
             DVSOF_LAUNCH_CHECK();
         }
     }
@@ -312,7 +361,7 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
 
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias)
 {
-    const int S = wgrad_splits(P, nullptr);
-    if (S <= 1) return 0;
-    return (size_t)S * ((size_t)P.Cout * P.ks * P.ks * P.Cin_tot + (with_bias ? P.Cout : 0));
+    const int nslab = wgrad_splits(P, nullptr) * P.nph;
+    if (nslab <= 1) return 0;
+    return (size_t)nslab * ((size_t)P.Cout * P.ks * P.ks * P.Cin_tot + (with_bias ? P.Cout : 0));
 }

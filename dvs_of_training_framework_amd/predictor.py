@@ -97,8 +97,12 @@ class _PredictorFn(torch.autograd.Function):
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
             d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act)
-            y, z = C.conv_fwd(d, _phys(wgt), bias, dev, residual, mish)
-            L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt))
+            # prepared weights: sub-pixel phase kernels for the decoder, and
+            # (when training) the data-gradient form, made once per step
+            first = len(L) == 0       # voxel input needs no data gradient
+            w_fwd, w_dg = C.prepare(d, _phys(wgt), want_grad and not first)
+            y, z = C.conv_fwd(d, w_fwd, bias, dev, residual, mish)
+            L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg))
             return y
 
         # encoder
@@ -143,9 +147,7 @@ class _PredictorFn(torch.autograd.Function):
             return layer['z'] if mish else layer['y']
 
         def wt(layer):
-            d = layer['desc']
-            ctot = sum(s[1] for s in layer['srcs'])
-            return C.flip_transpose(_phys(layer['w']), d.Cout, d.ksize, ctot)
+            return layer['w_dg']
 
         def new(t):
             return torch.empty_like(t)

@@ -170,7 +170,24 @@ typedef struct {
     int act; /* DVSOF_ACT_* */
 } dvsof_conv_desc_t;
 
-/* y (and z = pre-activation, optional, for Mish backward) are NHWC. */
+/*
+ * Prepared weights.  An upsampled 3x3/pad-1 layer is evaluated as four 2x2
+ * sub-pixel phase convolutions on the low-resolution input (2.25x fewer
+ * multiply-adds, same result up to fp32 summation order); its forward
+ * weights are Wf[4][Cout][2][2][Ctot] and its data-gradient weights the 4x4
+ * stride-2 kernel Wd[Ctot][4][4][Cout].  Every other layer uses the raw
+ * weights forward and their tap-flipped transpose backward.
+ * dvsof_conv2d_prepare fills w_fwd (may be NULL when
+ * dvsof_conv2d_fwd_weight_elems == Cout*k*k*Ctot: forward then takes the raw
+ * weights) and w_dgrad (may be NULL) from the raw [Cout][k][k][Ctot] weights.
+ */
+size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *desc);
+size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *desc);
+int dvsof_conv2d_prepare(const dvsof_conv_desc_t *desc, const float *weight,
+                         float *w_fwd, float *w_dgrad, void *stream);
+
+/* weight = prepared forward weights (see above).
+ * y (and z = pre-activation, optional, for Mish backward) are NHWC. */
 int dvsof_conv2d_fwd(const dvsof_conv_desc_t *desc, const float *weight,
                      const float *bias, const float *residual, float *y,
                      float *z, void *stream);
@@ -186,8 +203,8 @@ typedef struct {
 /*
  * Data gradient: for every source i, dst[i].p = d loss / d src[i] given
  * gout = d loss / d (pre-activation output) [B,Ho,Wo,Cout] NHWC.
- * weight_t is the tap-flipped transpose [Ctot][ksize][ksize][Cout] made by
- * dvsof_weight_flip_transpose.  dst[i].p == NULL skips nothing (all sources
+ * weight_t is the prepared data-gradient weight (dvsof_conv2d_prepare; for a
+ * plain layer the tap-flipped transpose [Ctot][ksize][ksize][Cout]).  dst[i].p == NULL skips nothing (all sources
  * are computed together); pass a scratch buffer if a gradient is not needed.
  */
 int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *desc, const float *weight_t,

@@ -86,7 +86,9 @@ def test_conv_fwd_dgrad_wgrad(ci):
     ho, wo = C.out_size(desc)
     res = torch.randn(case['B'], case['Cout'], ho, wo) if case.get('residual') else None
     y_ref, z_ref = torch_fwd(xs, w, b, o, act, C, res)
-    y, z = C.conv_fwd(desc, wphys(w), b.cuda(), 'cuda',
+    w_dev = wphys(w.detach())
+    w_fwd, wt = C.prepare(desc, w_dev, True)     # sub-pixel forms for up-layers
+    y, z = C.conv_fwd(desc, w_fwd, b.cuda(), 'cuda',
                       nhwc(res) if res is not None else None, want_z=True)
     close(from_nhwc(y), y_ref)
     close(from_nhwc(z), z_ref)
@@ -95,7 +97,6 @@ def test_conv_fwd_dgrad_wgrad(ci):
     z_ref.backward(gz)
     gz_d = nhwc(gz)
     ctot = sum(c for c, _ in case['src'])
-    wt = C.flip_transpose(wphys(w.detach()), case['Cout'], o['k'], ctot)
     dsts, holders = [], []
     for x, (c, lay) in zip(xs, case['src']):
         buf = torch.empty(x.shape if lay == 'nchw' else
@@ -124,7 +125,7 @@ def test_dgrad_epilogue_addends_and_act():
     ysrc = torch.randn(x.shape)
     want = (x.grad + a1 + a2) * (ysrc > 0).float()
     buf = torch.empty(2, 8, 8, 32, device='cuda')
-    wt = C.flip_transpose(wphys(w), 64, 3, 32)
+    _, wt = C.prepare(desc, wphys(w), True)
     C.conv_dgrad(desc, wt, nhwc(gz), [dict(p=buf, addend=nhwc(a1), addend2=nhwc(a2),
                                            actsrc=nhwc(ysrc))], C.ACT_RELU)
     close(from_nhwc(buf), want)
