@@ -118,6 +118,39 @@ __global__ __launch_bounds__(256) void subpixel_dgrad_weights_kernel(const float
     }
 }
 
+// Stride-2 3x3/pad-1 data gradient as four input-parity phases of 2x2 taps:
+// Wp[ph][ci][a][b][co] = W[co][ky(py,a)][kx(px,b)][ci], ky(0,0)=1, ky(0,1)=none,
+// ky(1,0)=2, ky(1,1)=0 (unused taps are zero).  ph = 2*py + px.
+__global__ __launch_bounds__(256) void stride2_dgrad_weights_kernel(const float *__restrict__ w,
+                                                                    float *__restrict__ wp,
+                                                                    int Cout, int Ctot)
+{
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z;            // ph*4 + a*2 + b
+    const int ph = z >> 2, a = (z >> 1) & 1, b = z & 1, py = ph >> 1, px = ph & 1;
+    const int ky = py ? (a ? 0 : 2) : (a ? -1 : 1), kx = px ? (b ? 0 : 2) : (b ? -1 : 1);
+    const bool used = ky >= 0 && kx >= 0;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + lx;
+        tile[r][lx] = (used && co < Cout && ci < Ctot)
+                          ? w[((size_t)co * 9 + ky * 3 + kx) * Ctot + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + lx;
+        if (ci < Ctot && co < Cout)
+            wp[(((size_t)ph * Ctot + ci) * 4 + a * 2 + b) * Cout + co] = tile[lx][r];
+    }
+}
+
+bool is_stride2_phased(const dvsof_conv_desc_t *d)
+{
+    return !d->upsample && d->stride == 2 && d->ksize == 3 && d->pad == 1 &&
+           (d->H % 2 == 0) && (d->W % 2 == 0);
+}
+
 __global__ __launch_bounds__(256) void flip_transpose_kernel(const float *__restrict__ w,
                                                              float *__restrict__ wt, int Cout,
                                                              int taps, int Ctot)
@@ -239,17 +272,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         part[(size_t)blockIdx.x * (2 * C + 2) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-// dw[2*C], dbias[2] from the per-workgroup partials, fixed order
+// dw[2*C], dbias[2] from the per-workgroup partials, fixed order: one wave
+// per output column, lanes stride over the workgroups, shuffle tree.
 __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const float *__restrict__ part,
                                                               int nblocks, int C, float *dw,
                                                               float *dbias)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= 2 * C + 2) return;
     double a = 0;
-    for (int b = 0; b < nblocks; ++b) a += (double)part[(size_t)b * (2 * C + 2) + i];
-    if (i < 2 * C) dw[i] = (float)a;
-    else if (dbias) dbias[i - 2 * C] = (float)a;
+    for (int b = lane; b < nblocks; b += 64) a += (double)part[(size_t)b * (2 * C + 2) + i];
+    a = wave_sum(a);
+    if (lane == 0) {
+        if (i < 2 * C) dw[i] = (float)a;
+        else if (dbias) dbias[i - 2 * C] = (float)a;
+    }
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *dy,
@@ -424,6 +461,26 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         P.ks = 4;
         P.stride = 2;
         P.pad = 1;
+    } else if (is_stride2_phased(d)) {
+        // four input-parity phases, each a 2x2-tap stride-1 conv of gout
+        // (weights prepared as Wp[4][Ctot][2][2][Cout]); rows = (H/2 x W/2)
+        P.up = UP_NONE;
+        P.Hv = Ho;
+        P.Wv = Wo;
+        P.Ho = d->H / 2;
+        P.Wo = d->W / 2;
+        P.quad = 0;
+        P.ks = 2;
+        P.stride = 1;
+        P.pad = 0;
+        P.nph = 4;
+        P.w_phase_stride = (long long)Ctot * 4 * d->Cout;
+        for (int i = 0; i < d->nsrc; ++i) {
+            P.dst[i].ph_y = P.dst[i].sy;
+            P.dst[i].ph_x = P.dst[i].sx;
+            P.dst[i].sy *= 2;
+            P.dst[i].sx *= 2;
+        }
     } else if (d->upsample) {  // rows = upsampled pixels, quad-summed to H x W
         P.up = UP_NONE;
         P.Hv = Ho;
@@ -480,7 +537,10 @@ size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *d)
 
 size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *d)
 {
-    return dvsof_conv2d_fwd_weight_elems(d);
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
+    if (is_subpixel(d) || is_stride2_phased(d)) return (size_t)d->Cout * Ctot * 16;
+    return (size_t)d->Cout * Ctot * d->ksize * d->ksize;
 }
 
 int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float *w_fwd,
@@ -503,6 +563,16 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
         }
         return DVSOF_OK;
     }
+    if (is_stride2_phased(d) && w_dgrad) {
+        if (w_fwd && w_fwd != weight)
+            DVSOF_HIP_TRY(hipMemcpyAsync(w_fwd, weight, (size_t)d->Cout * 9 * Ctot * sizeof(float),
+                                         hipMemcpyDeviceToDevice, st));
+        dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);
+        hipLaunchKernelGGL(stride2_dgrad_weights_kernel, grid, dim3(256), 0, st, weight, w_dgrad,
+                           d->Cout, Ctot);
+        DVSOF_LAUNCH_CHECK();
+        return DVSOF_OK;
+    }
     if (w_fwd && w_fwd != weight)
         DVSOF_HIP_TRY(hipMemcpyAsync(w_fwd, weight, dvsof_conv2d_fwd_weight_elems(d) * sizeof(float),
                                      hipMemcpyDeviceToDevice, st));
@@ -517,7 +587,7 @@ int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)
     if (kind == 0) return gconv_pick_tile((long long)d->B * Ho * Wo, d->Cout);
     if (kind == 1) {
         const int up = (d->upsample && !is_subpixel(d)) ? 2 : 1;
-        return gconv_pick_tile((long long)d->B * d->H * up * d->W * up, Ctot);
+        return gconv_pick_tile((long long)d->B * d->H * up * d->W * up, Ctot);  // phases included
     }
     if (kind == 2) {
         WGradParams P;
@@ -582,7 +652,7 @@ int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow, cons
     float *part = (float *)ws;
     HEAD_DISPATCH(head_bwd_kernel, nb, x, w, gflow, gx_in, actsrc, act, gx, part, B, H * W);
     DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((2 * C + 2 + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((2 * C + 2 + 3) / 4), dim3(256), 0, st,
                        (const float *)part, nb, C, dw, dbias);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;

@@ -323,17 +323,18 @@ int gconv_pick_tile(long long m, long long n)
     // candidates: id, BM, BN.  Cost = padded MACs, with a penalty for grids
     // that cannot fill 256 CUs and a mild preference for larger tiles.
     static const int cand[5][3] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {4, 256, 32}, {5, 128, 32}};
+    // base efficiency of each tile shape (operand reuse per MFMA)
+    static const double eff[5] = {1.0, 0.95, 0.85, 0.85, 0.75};
     int best = 3;
     double best_cost = 1e300;
     for (int i = 0; i < 5; ++i) {
         const int bm = cand[i][1], bn = cand[i][2];
         const long long tm = (m + bm - 1) / bm, tn = (n + bn - 1) / bn;
-        const long long blocks = tm * tn;
-        double cost = (double)tm * bm * (double)tn * bn;
-        const long long waves = (blocks + 255) / 256;          // rounds of 256 CUs
-        cost *= (double)(waves * 256) / (double)blocks;        // tail/under-fill
-        if (bn == 32) cost *= 1.25;                            // low operand reuse
-        else if (bm * bn == 64 * 64) cost *= 1.10;
+        const double blocks = (double)(tm * tn);
+        double cost = (double)tm * bm * (double)tn * bn / eff[i];
+        // one workgroup per CU cannot hide load latency: want >= 2 per CU
+        const double bpc = blocks / 256.0;
+        if (bpc < 2.0) cost *= 2.0 / (bpc < 0.25 ? 0.25 : bpc);
         if (cost < best_cost) {
             best_cost = cost;
             best = cand[i][0];
