@@ -28,6 +28,7 @@
 // h = lane>>5 reads k = 8j + 4h .. +3 as one b128 and feeds 4 consecutive
 // MFMAs; A and B use the same k permutation, so the sum is unchanged.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -343,6 +344,9 @@ int gconv_pick_tile(long long m, long long n)
     return best;
 }
 
+bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_bytes);
+int gconv2_launch(const GConvParams &P, int tile, hipStream_t st);
+
 // Internal entry (not part of the C ABI): picks the tile shape and launches.
 int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
 {
@@ -354,6 +358,16 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
     const int tile = tile_hint > 0 ? tile_hint : gconv_pick_tile((long long)P.M * P.nph, P.N);
+    {   // v2 (LDS-DMA ring, VALU-free main loop) when the shape allows it
+        static const bool force_v1 = getenv("DVSOF_GCONV_V1") != nullptr;
+        long long src_bytes = 0;
+        for (int s = 0; s < P.nsrc; ++s) {
+            const long long b = (long long)P.B * P.src[s].sb * 4;
+            src_bytes = b > src_bytes ? b : src_bytes;
+        }
+        const long long w_bytes = (long long)P.N * P.ks * P.ks * P.Cin_tot * 4 * P.nph;
+        if (!force_v1 && gconv2_eligible(P, src_bytes, w_bytes)) return gconv2_launch(P, tile, st);
+    }
     switch (tile) {
     case 1: return launch<2, 2, 2, 2>(P, st);  // 128 x 128
     case 2: return launch<2, 2, 2, 1>(P, st);  // 128 x 64

@@ -1,0 +1,420 @@
+// gconv v2: the gather-convolution implicit GEMM with a VALU-free main loop.
+//
+// Measured on gfx950 (tools/ubench/mfma_valu.hip): v_mfma_f32_32x32x2_f32
+// shares the SIMD's vector datapath -- every VALU instruction, from the same
+// or a co-resident wave, delays the MFMA stream by ~4 cycles (pure MFMA loop
+// 140 TF/s; +8 v_fma per MFMA: 96 TF/s).  So the K loop here issues, per
+// 16-wide K slice and wave, only: MFMAs, ds_read_b128 with immediate offsets,
+// `buffer_load_dwordx4 ... lds` (LDS-DMA) with SGPR offsets, one counted
+// s_waitcnt and one s_barrier.
+//
+//   * operands go HBM/L2 -> LDS directly (no VGPR staging, no ds_write) into a
+//     ring of NS stages; loads run NS-1 slices ahead of the MFMAs;
+//   * the per-lane byte offset (voffset) of every load slot depends only on
+//     (row, tap): it is recomputed on tap changes; the channel-chunk offset
+//     advances in an SGPR (soffset);
+//   * taps that fall outside the frame, zero-inserted positions and rows past
+//     M get voffset = 0x80000000: the buffer range check returns zeros;
+//   * an LDS-DMA writes lane-linear 1 KiB pieces (16 rows x 64 B); the
+//     conflict-free image is obtained by permuting which 16-byte k-quad a lane
+//     FETCHES (slot s of row r holds k-quad s ^ ((r>>2)&3)) and applying the
+//     same XOR on the read side;
+//   * "flat" concat members (NCHW planar or C < 16: the 5-bin voxel grid, the
+//     2-channel flow) are few K slices: they run first through a synchronous
+//     register path into the same LDS image.
+//
+// Same GConvParams / epilogue semantics as gconv.hip (v1), which stays as the
+// fallback for shapes this kernel does not take (see gconv2_eligible).
+#include "conv_common.h"
+
+namespace {
+
+constexpr int NS = 4;               // ring stages
+constexpr unsigned OOB = 0x80000000u;
+
+struct KIt {
+    int s, tap, c0, coff;
+};
+
+template <int WROWS, int WCOLS, int TM, int TN>
+__global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, const int nflat,
+                                                         const int nvec)
+{
+    constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    // pieces of 16 rows; the B load tile is padded so that every wave issues
+    // the same number of LDS-DMA instructions per stage
+    constexpr int PA = BM / 16;
+    constexpr int PB0 = (BN + 15) / 16;
+    constexpr int PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
+    constexpr int LPW = (PA + PB) / 4;            // loads per wave per stage
+    constexpr int STAGE = (PA + PB) * 1024;       // bytes
+    constexpr int ROWINFO = NS * STAGE;           // byte offset of rowB/rowY/rowX
+    static_assert(WROWS * WCOLS == CONV_NT / kWave, "4 waves");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    int *rowB = (int *)(smem + ROWINFO), *rowY = rowB + BM, *rowX = rowY + BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int taps = P.ks * P.ks;
+    const int ph = blockIdx.z, phy = ph >> 1, phx = ph & 1;
+    const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
+    const float *Wp = P.W + (size_t)ph * P.w_phase_stride;
+    const size_t wrow = (size_t)taps * P.Cin_tot;
+
+    for (int r = tid; r < BM; r += CONV_NT) {
+        const int m = m0 + r;
+        int b = 0, y = -(1 << 20), x = -(1 << 20);
+        if (m < P.M) {
+            int oy, ox;
+            if (!P.quad) {
+                ox = m % P.Wo;
+                const int t = m / P.Wo;
+                oy = t % P.Ho;
+                b = t / P.Ho;
+            } else {
+                const int j = m & 3, q = m >> 2, wq = P.Wo >> 1, hq = P.Ho >> 1;
+                const int t = q / wq;
+                ox = 2 * (q - t * wq) + (j & 1);
+                oy = 2 * (t % hq) + (j >> 1);
+                b = t / hq;
+            }
+            y = oy * P.stride - pad_y;
+            x = ox * P.stride - pad_x;
+        }
+        rowB[r] = b;
+        rowY[r] = y;
+        rowX[r] = x;
+    }
+    __syncthreads();
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment read addresses (bytes inside a stage): row R, k-quad q = 2j + h
+    // lives in slot q ^ ((R>>2)&3)
+    const int lrow = lane & 31, lh = lane >> 5;
+    int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int R = (wr * TM + t) * 32 + lrow;
+            a_off[t][j] = R * 64 + (((2 * j + lh) ^ ((R >> 2) & 3)) << 4);
+        }
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int R = (wc * TN + t) * 32 + lrow;
+            b_off[t][j] = PA * 1024 + R * 64 + (((2 * j + lh) ^ ((R >> 2) & 3)) << 4);
+        }
+
+    auto compute = [&](const unsigned char *stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = *(const f32x4 *)(stage + a_off[t][j]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = *(const f32x4 *)(stage + b_off[t][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i],
+                                                                           acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+    // ------------------------------------------------------------------
+    // flat concat members first: synchronous register path into stage 0
+    // ------------------------------------------------------------------
+    if (nflat > 0) {
+        int s = 0, coff = 0, f0 = 0, done = 0;
+        while (!P.src[s].flat) {
+            coff += P.src[s].C;
+            ++s;
+        }
+        while (done < nflat) {
+            const GSrc &S = P.src[s];
+            const int f = f0 + (tid & 15);
+            const bool fok = f < taps * S.C;
+            const int tap = fok ? f / S.C : 0, c = f - tap * S.C;
+            const int ky = tap / P.ks, kx = tap - ky * P.ks;
+            const int kk = tid & 15;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < BM / 16; ++i) {
+                const int r = (tid >> 4) + 16 * i;
+                const int Y = rowY[r] + ky, X = rowX[r] + kx;
+                bool ok = fok & ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+                if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
+                float v = 0.f;
+                if (ok) {
+                    const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
+                    v = S.p[(size_t)rowB[r] * S.sb + (size_t)ys * S.sy + (size_t)xs * S.sx +
+                            (size_t)c * S.sc];
+                }
+                *(float *)(smem + r * 64 + ((((kk >> 2) ^ ((r >> 2) & 3))) << 4) + (kk & 3) * 4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 16; ++i) {
+                const int r = (tid >> 4) + 16 * i, n = n0 + r;
+                const float v = (fok && n < P.N)
+                                    ? Wp[(size_t)n * wrow + (size_t)tap * P.Cin_tot + coff + c] : 0.f;
+                *(float *)(smem + PA * 1024 + r * 64 + ((((kk >> 2) ^ ((r >> 2) & 3))) << 4) +
+                           (kk & 3) * 4) = v;
+            }
+            __syncthreads();
+            compute(smem);
+            ++done;
+            f0 += BK;
+            if (f0 >= taps * S.C) {  // next flat member
+                f0 = 0;
+                coff += S.C;
+                ++s;
+                while (done < nflat && !P.src[s].flat) {
+                    coff += P.src[s].C;
+                    ++s;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------
+    // vector members: LDS-DMA ring
+    // ------------------------------------------------------------------
+    if (nvec > 0) {
+        // load slots of this wave: piece p = wave + 4*i, i < LPW
+        //   p < PA : A rows 16p .. 16p+15 ; else B rows 16(p-PA) ..
+        // lane -> row 16p + (lane>>2), slot lane&3, fetched k-quad slot ^ ((row>>2)&3)
+        int slot_row[LPW];
+        unsigned slot_kq4[LPW];       // byte offset of the fetched k-quad
+        unsigned voff[LPW];
+        int sb_[LPW], sy_[LPW], sx_[LPW];   // row info of A slots
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int p = wave + 4 * i;
+            const int r = (p < PA ? 16 * p : 16 * (p - PA)) + (lane >> 2);
+            slot_row[i] = r;
+            slot_kq4[i] = (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) << 4);
+            if (p < PA) {
+                sb_[i] = rowB[r];
+                sy_[i] = rowY[r];
+                sx_[i] = rowX[r];
+                voff[i] = OOB;
+            } else {
+                const int n = n0 + r;
+                sb_[i] = sy_[i] = sx_[i] = 0;
+                voff[i] = (r < BN && n < P.N) ? (unsigned)(n * wrow * 4) + slot_kq4[i] : OOB;
+            }
+        }
+        const __amdgpu_buffer_rsrc_t wres =
+            __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, 0x7fffffff, 0x00020000);
+
+        KIt it = {0, 0, 0, 0};
+        while (P.src[it.s].flat) {
+            it.coff += P.src[it.s].C;
+            ++it.s;
+        }
+        int cur_tap = -1, cur_src = -1;
+        __amdgpu_buffer_rsrc_t ares =
+            __builtin_amdgcn_make_buffer_rsrc((void *)P.src[it.s].p, 0, 0x7fffffff, 0x00020000);
+
+        auto issue = [&](int stage_idx) {
+            // (re)compute the per-lane offsets of the A slots on a tap change
+            if (it.tap != cur_tap || it.s != cur_src) {
+                const GSrc &S = P.src[it.s];
+                if (it.s != cur_src)
+                    ares = __builtin_amdgcn_make_buffer_rsrc((void *)S.p, 0, 0x7fffffff, 0x00020000);
+                cur_tap = it.tap;
+                cur_src = it.s;
+                const int ky = it.tap / P.ks, kx = it.tap - ky * P.ks;
+#pragma unroll
+                for (int i = 0; i < LPW; ++i) {
+                    if (wave + 4 * i < PA) {
+                        const int Y = sy_[i] + ky, X = sx_[i] + kx;
+                        bool ok = ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+                        if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
+                        const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
+                        const unsigned o = (unsigned)(((long long)sb_[i] * S.sb + (long long)ys * S.sy +
+                                                       (long long)xs * S.sx) * 4) + slot_kq4[i];
+                        voff[i] = ok ? o : OOB;
+                    }
+                }
+            }
+            const int a_soff = it.c0 * 4;
+            const int b_soff = (it.tap * P.Cin_tot + it.coff + it.c0) * 4;
+            unsigned char *st = smem + stage_idx * STAGE;
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) {
+                const int p = wave + 4 * i;     // wave-uniform
+                __attribute__((address_space(3))) void *dst =
+                    (__attribute__((address_space(3))) void *)(st + p * 1024);
+                if (p < PA)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, dst, 16, voff[i], a_soff, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, voff[i], b_soff, 0, 0);
+            }
+            // advance (chunk inner, tap, then next vector member)
+            it.c0 += BK;
+            if (it.c0 >= P.src[it.s].C) {
+                it.c0 = 0;
+                it.tap += 1;
+                if (it.tap >= taps) {
+                    it.tap = 0;
+                    it.coff += P.src[it.s].C;
+                    ++it.s;
+                    while (it.s < P.nsrc && P.src[it.s].flat) {
+                        it.coff += P.src[it.s].C;
+                        ++it.s;
+                    }
+                }
+            }
+        };
+
+        // prologue: NS-1 slices in flight
+#pragma unroll
+        for (int u = 0; u < NS - 1; ++u)
+            if (u < nvec) issue(u);
+
+        for (int s0 = 0; s0 < nvec; s0 += NS) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int s = s0 + u;
+                if (s < nvec) {
+                    // slice s has landed when at most the younger slices' loads remain
+                    if (s + NS - 1 <= nvec) {
+                        if (s + NS - 2 < nvec) {
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPW) : "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    if (s + NS - 1 < nvec) issue((u + NS - 1) % NS);
+                    compute(smem + u * STAGE);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue (as in gconv.hip)
+    const int sshift = P.stride - 1;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wc * TN + tn) * 32 + lrow;
+        if (n >= P.N) continue;
+        int d = 0, off = 0;
+        for (int dd = 0; dd + 1 < P.ndst; ++dd)
+            if (n >= off + P.dst[dd].C && d == dd) {
+                off += P.dst[dd].C;
+                d = dd + 1;
+            }
+        const GDst &D = P.dst[d];
+        const int c = n - off;
+        const float bias = P.bias ? P.bias[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int rbase = (wr * TM + tm) * 32 + 4 * (lane >> 5);
+            if (!P.quad) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+                    if (m0 + row >= P.M) continue;
+                    const int oy = (rowY[row] + pad_y) >> sshift, ox = (rowX[row] + pad_x) >> sshift;
+                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)oy * D.sy +
+                                     (size_t)ox * D.sx + (size_t)c * D.sc + phy * D.ph_y +
+                                     phx * D.ph_x;
+                    float v = acc[tm][tn][reg] + bias;
+                    if (D.addend) v += D.addend[o];
+                    if (D.addend2) v += D.addend2[o];
+                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
+                    if (P.zout) P.zout[o] = v;
+                    D.p[o] = act_fwd(v, P.act);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rbase + 8 * g;
+                    if (m0 + row >= P.M) continue;
+                    const int y = (rowY[row] + pad_y) >> 1, x = (rowX[row] + pad_x) >> 1;
+                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)y * D.sy +
+                                     (size_t)x * D.sx + (size_t)c * D.sc;
+                    float v = (acc[tm][tn][4 * g] + acc[tm][tn][4 * g + 1]) +
+                              (acc[tm][tn][4 * g + 2] + acc[tm][tn][4 * g + 3]) + bias;
+                    if (D.addend) v += D.addend[o];
+                    if (D.addend2) v += D.addend2[o];
+                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
+                    D.p[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WROWS, int WCOLS, int TM, int TN>
+int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
+{
+    constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    constexpr int PA = BM / 16, PB0 = (BN + 15) / 16, PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
+    constexpr size_t LDS = (size_t)NS * (PA + PB) * 1024 + 3 * BM * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_set = true;
+    }
+    dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN, P.nph);
+    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), LDS, st, P, nflat,
+                       nvec);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+}  // namespace
+
+// v2 takes problems whose vector members have 16-aligned channel counts and
+// whose tensors are addressable with 31-bit byte offsets.
+bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_bytes)
+{
+    bool any_vec = false;
+    for (int s = 0; s < P.nsrc; ++s) {
+        if (P.src[s].flat) continue;
+        any_vec = true;
+        if (P.src[s].sc != 1 || (P.src[s].C % BK)) return false;
+    }
+    if (!any_vec) return false;
+    if (max_src_bytes >= 0x7fffffffLL || w_bytes >= 0x7fffffffLL) return false;
+    return true;
+}
+
+int gconv2_launch(const GConvParams &P, int tile, hipStream_t st)
+{
+    const int taps = P.ks * P.ks;
+    int nflat = 0, nvec = 0;
+    for (int s = 0; s < P.nsrc; ++s) {
+        if (P.src[s].flat) nflat += (taps * P.src[s].C + BK - 1) / BK;
+        else nvec += taps * (P.src[s].C / BK);
+    }
+    switch (tile) {
+    case 1: return launch2<2, 2, 2, 2>(P, nflat, nvec, st);  // 128 x 128
+    case 2: return launch2<2, 2, 2, 1>(P, nflat, nvec, st);  // 128 x 64
+    case 3: return launch2<2, 2, 1, 1>(P, nflat, nvec, st);  // 64 x 64
+    case 4: return launch2<4, 1, 2, 1>(P, nflat, nvec, st);  // 256 x 32
+    case 5: return launch2<4, 1, 1, 1>(P, nflat, nvec, st);  // 128 x 32
+    default: return DVSOF_EINVAL;
+    }
+}
