@@ -36,10 +36,13 @@ struct KIt {
     int s, tap, c0, coff;
 };
 
+}  // namespace
+
 template <int WROWS, int WCOLS, int TM, int TN>
 __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, const int nflat,
                                                          const int nvec)
 {
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins/types below
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
     // pieces of 16 rows; the B load tile is padded so that every wave issues
     // the same number of LDS-DMA instructions per stage
@@ -363,7 +366,10 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
             }
         }
     }
+#endif  // __HIP_DEVICE_COMPILE__
 }
+
+namespace {
 
 template <int WROWS, int WCOLS, int TM, int TN>
 int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
