@@ -57,7 +57,10 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     int *rowB = (int *)(smem + ROWINFO), *rowY = rowB + BM, *rowX = rowY + BM;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform values must live in SGPRs: otherwise hipcc wraps every
+    // LDS-DMA in a waterfall loop over "possibly divergent" descriptors
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int taps = P.ks * P.ks;
@@ -120,22 +123,26 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
         }
 
     auto compute = [&](const unsigned char *stage) {
+        // all fragment reads of the slice are issued before the first MFMA so
+        // that only the first pair's LDS latency is exposed
+        f32x4 a[2][TM], b[2][TN];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = *(const f32x4 *)(stage + a_off[t][j]);
+            for (int t = 0; t < TM; ++t) a[j][t] = *(const f32x4 *)(stage + a_off[t][j]);
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = *(const f32x4 *)(stage + b_off[t][j]);
+            for (int t = 0; t < TN; ++t) b[j][t] = *(const f32x4 *)(stage + b_off[t][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i],
-                                                                           acc[tm][tn], 0, 0, 0);
-        }
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            a[j][tm][i], b[j][tn][i], acc[tm][tn], 0, 0, 0);
     };
 
     // ------------------------------------------------------------------
@@ -225,43 +232,43 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
         const __amdgpu_buffer_rsrc_t wres =
             __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, 0x7fffffff, 0x00020000);
 
-        KIt it = {0, 0, 0, 0};
-        while (P.src[it.s].flat) {
-            it.coff += P.src[it.s].C;
-            ++it.s;
+        // K-slice iterator, all in SGPRs: member s, tap (ky,kx), chunk c0
+        int it_s = 0, it_coff = 0;
+        while (P.src[it_s].flat) {
+            it_coff += P.src[it_s].C;
+            ++it_s;
         }
-        int cur_tap = -1, cur_src = -1;
+        int it_ky = 0, it_kx = 0, it_c0 = 0;
+        int it_C = P.src[it_s].C;
+        bool new_tap = true;
+        long long a_sb = P.src[it_s].sb;
+        int a_sy = P.src[it_s].sy, a_sx = P.src[it_s].sx;
         __amdgpu_buffer_rsrc_t ares =
-            __builtin_amdgcn_make_buffer_rsrc((void *)P.src[it.s].p, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *)P.src[it_s].p, 0, 0x7fffffff, 0x00020000);
 
         auto issue = [&](int stage_idx) {
-            // (re)compute the per-lane offsets of the A slots on a tap change
-            if (it.tap != cur_tap || it.s != cur_src) {
-                const GSrc &S = P.src[it.s];
-                if (it.s != cur_src)
-                    ares = __builtin_amdgcn_make_buffer_rsrc((void *)S.p, 0, 0x7fffffff, 0x00020000);
-                cur_tap = it.tap;
-                cur_src = it.s;
-                const int ky = it.tap / P.ks, kx = it.tap - ky * P.ks;
+            if (new_tap) {  // per-lane offsets of the A slots for this (member, tap)
+                new_tap = false;
 #pragma unroll
                 for (int i = 0; i < LPW; ++i) {
                     if (wave + 4 * i < PA) {
-                        const int Y = sy_[i] + ky, X = sx_[i] + kx;
+                        const int Y = sy_[i] + it_ky, X = sx_[i] + it_kx;
                         bool ok = ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
                         if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
                         const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
-                        const unsigned o = (unsigned)(((long long)sb_[i] * S.sb + (long long)ys * S.sy +
-                                                       (long long)xs * S.sx) * 4) + slot_kq4[i];
+                        const unsigned o = (unsigned)(((long long)sb_[i] * a_sb + (long long)ys * a_sy +
+                                                       (long long)xs * a_sx) * 4) + slot_kq4[i];
                         voff[i] = ok ? o : OOB;
                     }
                 }
             }
-            const int a_soff = it.c0 * 4;
-            const int b_soff = (it.tap * P.Cin_tot + it.coff + it.c0) * 4;
+            const int a_soff = __builtin_amdgcn_readfirstlane(it_c0 * 4);
+            const int b_soff = __builtin_amdgcn_readfirstlane(
+                ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff + it_c0) * 4);
             unsigned char *st = smem + stage_idx * STAGE;
 #pragma unroll
             for (int i = 0; i < LPW; ++i) {
-                const int p = wave + 4 * i;     // wave-uniform
+                const int p = wave + 4 * i;     // SGPR
                 __attribute__((address_space(3))) void *dst =
                     (__attribute__((address_space(3))) void *)(st + p * 1024);
                 if (p < PA)
@@ -269,18 +276,29 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, voff[i], b_soff, 0, 0);
             }
-            // advance (chunk inner, tap, then next vector member)
-            it.c0 += BK;
-            if (it.c0 >= P.src[it.s].C) {
-                it.c0 = 0;
-                it.tap += 1;
-                if (it.tap >= taps) {
-                    it.tap = 0;
-                    it.coff += P.src[it.s].C;
-                    ++it.s;
-                    while (it.s < P.nsrc && P.src[it.s].flat) {
-                        it.coff += P.src[it.s].C;
-                        ++it.s;
+            // advance: chunk inner, then tap, then the next vector member
+            it_c0 += BK;
+            if (it_c0 >= it_C) {
+                it_c0 = 0;
+                new_tap = true;
+                if (++it_kx == P.ks) {
+                    it_kx = 0;
+                    if (++it_ky == P.ks) {
+                        it_ky = 0;
+                        it_coff += it_C;
+                        ++it_s;
+                        while (it_s < P.nsrc && P.src[it_s].flat) {
+                            it_coff += P.src[it_s].C;
+                            ++it_s;
+                        }
+                        if (it_s < P.nsrc) {
+                            it_C = P.src[it_s].C;
+                            a_sb = P.src[it_s].sb;
+                            a_sy = P.src[it_s].sy;
+                            a_sx = P.src[it_s].sx;
+                            ares = __builtin_amdgcn_make_buffer_rsrc((void *)P.src[it_s].p, 0,
+                                                                     0x7fffffff, 0x00020000);
+                        }
                     }
                 }
             }

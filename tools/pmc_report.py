@@ -8,9 +8,9 @@ dirs = sys.argv[1:]
 frames = []
 for d in dirs:
     c = pd.read_csv(f'gpurun_out/{d}/pmc_counter_collection.csv')
-    c = c[c.Kernel_Name.str.contains('gconv_kernel|wgrad_kernel')]
+    c = c[c.Kernel_Name.str.contains('gconv2?_kernel|wgrad_kernel')]
     c['dur_us'] = (c.End_Timestamp - c.Start_Timestamp) / 1e3
-    c['k'] = c.Kernel_Name.str.extract(r'(gconv_kernel<[^>]*>|wgrad_kernel<[^>]*>)')[0].str.replace(' ', '')
+    c['k'] = c.Kernel_Name.str.extract(r'(gconv2?_kernel<[^>]*>|wgrad_kernel<[^>]*>)')[0].str.replace(' ', '')
     p = c.pivot_table(index=['Dispatch_Id', 'k', 'Grid_Size', 'VGPR_Count', 'LDS_Block_Size'],
                       columns='Counter_Name', values='Counter_Value', aggfunc='sum')
     p['dur_us'] = c.groupby(['Dispatch_Id', 'k', 'Grid_Size', 'VGPR_Count', 'LDS_Block_Size']).dur_us.first()
