@@ -14,6 +14,10 @@
 // lane (consecutive lanes -> consecutive banks); at 64 cycles per MFMA the
 // reads are far off the critical path.
 #include "conv_common.h"
+#include <stdlib.h>
+
+bool wgrad2_eligible(const WGradParams &P);
+int wgrad2_launch(const WGradParams &P, int tile, int ntiles, hipStream_t st);
 
 
 namespace {
@@ -206,6 +210,43 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_kernel(const WGradParams P)
     }
 }
 
+constexpr int COLSUM_MAX_BLOCKS = 512;
+
+int colsum_blocks(long long rows)
+{
+    const long long nb = (rows + 63) / 64;
+    return (int)(nb < 1 ? 1 : nb > COLSUM_MAX_BLOCKS ? COLSUM_MAX_BLOCKS : nb);
+}
+
+// part[block][c] = sum over this block's rows of g[row][c]   (g dense [rows][C])
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g, long long rows,
+                                                     int C, float *__restrict__ part)
+{
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per;
+    const long long r1 = r0 + per < rows ? r0 + per : rows;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        // 256 threads = G channel lanes x RP row lanes
+        const int G = (C - c0) < 256 ? (C - c0) : 256;
+        int RP = 256 / G;
+        if (RP < 1) RP = 1;
+        const int c = tid % G, rl = tid / G;
+        float a = 0.f;
+        if (rl < RP)
+            for (long long r = r0 + rl; r < r1; r += RP) a += g[r * C + c0 + c];
+        red[tid] = a;
+        __syncthreads();
+        if (tid < G) {
+            float t = 0.f;
+            for (int k = 0; k < RP; ++k) t += red[k * G + tid];
+            part[(size_t)blockIdx.x * C + c0 + tid] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // out[i] = sum_z slab[z][i], fixed order
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab,
                                                           float *__restrict__ out, size_t n, int S)
@@ -255,17 +296,26 @@ __global__ __launch_bounds__(256) void subpixel_fold_kernel(const float *__restr
     dW[i] = acc;
 }
 
-template <int WROWS, int WCOLS, int TM, int TN>
-int launch(WGradParams &P, hipStream_t st)
+// column tiles of the members selected by `want_flat` (others get none)
+int enumerate_tiles(WGradParams &P, int bn, int want_flat /* -1: all */)
 {
-    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
     const int taps = P.ks * P.ks;
     int t = 0;
     for (int s = 0; s < P.nsrc; ++s) {
         P.tile_begin[s] = t;
-        t += (taps * P.src[s].C + BN - 1) / BN;
+        if (want_flat < 0 || (P.src[s].flat != 0) == (want_flat != 0))
+            t += (taps * P.src[s].C + bn - 1) / bn;
     }
     P.tile_begin[P.nsrc] = t;
+    return t;
+}
+
+template <int WROWS, int WCOLS, int TM, int TN>
+int launch(WGradParams &P, int want_flat, hipStream_t st)
+{
+    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    const int t = enumerate_tiles(P, BN, want_flat);
+    if (t == 0) return DVSOF_OK;
     dim3 grid(t, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
     hipLaunchKernelGGL((wgrad_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
@@ -325,20 +375,41 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
     const int nslab = S * P.nph;
     const size_t wsize = (size_t)P.Cout * P.ks * P.ks * P.Cin_tot;
     const bool direct = nslab == 1;
-    const size_t need = direct ? 0 : (size_t)nslab * (wsize + (dbias ? P.Cout : 0));
+    const size_t need = (direct ? 0 : (size_t)nslab * wsize) +
+                        (dbias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
     if (need > ws_floats) return DVSOF_ENOSPACE;
     P.klen = (((P.M + S - 1) / S) + BK - 1) / BK * BK;
     P.dW = direct ? dW : ws;
-    P.dbias = dbias ? (direct ? dbias : ws + (size_t)nslab * wsize) : nullptr;
-    int rc;
+    P.dbias = nullptr;   // bias gradient: separate column-sum pass below
+    static const bool force_v1 = getenv("DVSOF_WGRAD_V1") != nullptr;
+    int want_flat = -1;  // v1 for everything ...
+    int rc = DVSOF_OK;
+    if (!force_v1 && wgrad2_eligible(P)) {  // ... or v2 for the vector members
+        int bm, bn;
+        tile_dims(tile, bm, bn);
+        const int nt = enumerate_tiles(P, bn, 0);
+        if (nt > 0) rc = wgrad2_launch(P, tile, nt, st);
+        if (rc) return rc;
+        want_flat = 1;
+    }
     switch (tile) {
-    case 1: rc = launch<2, 2, 2, 2>(P, st); break;
-    case 2: rc = launch<2, 2, 2, 1>(P, st); break;
-    case 3: rc = launch<2, 2, 1, 1>(P, st); break;
-    case 4: rc = launch<2, 2, 1, 2>(P, st); break;
-    default: rc = launch<1, 4, 1, 1>(P, st); break;
+    case 1: rc = launch<2, 2, 2, 2>(P, want_flat, st); break;
+    case 2: rc = launch<2, 2, 2, 1>(P, want_flat, st); break;
+    case 3: rc = launch<2, 2, 1, 1>(P, want_flat, st); break;
+    case 4: rc = launch<2, 2, 1, 2>(P, want_flat, st); break;
+    default: rc = launch<1, 4, 1, 1>(P, want_flat, st); break;
     }
     if (rc) return rc;
+    if (dbias) {  // column sums of gout (all phases cover gout exactly once)
+        const long long rows = (long long)P.B * (P.g_sb / P.Cout);
+        float *part = ws + (direct ? 0 : (size_t)nslab * wsize);
+        const int nb = colsum_blocks(rows);
+        hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, P.gout, rows, P.Cout, part);
+        DVSOF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((P.Cout + 1023) / 1024)), dim3(256),
+                           0, st, (const float *)part, dbias, (size_t)P.Cout, nb);
+        DVSOF_LAUNCH_CHECK();
+    }
     if (!direct) {
         if (P.nph == 4) {
             const size_t n = (size_t)P.Cout * 9 * P.Cin_tot;
@@ -349,12 +420,6 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
                                dim3(256), 0, st, (const float *)ws, dW, wsize, S);
         }
         DVSOF_LAUNCH_CHECK();
-        if (dbias) {
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((P.Cout + 1023) / 1024)),
-                               dim3(256), 0, st, (const float *)(ws + (size_t)nslab * wsize), dbias,
-                               (size_t)P.Cout, nslab);
-            DVSOF_LAUNCH_CHECK();
-        }
     }
     return DVSOF_OK;
 }
@@ -362,6 +427,6 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias)
 {
     const int nslab = wgrad_splits(P, nullptr) * P.nph;
-    if (nslab <= 1) return 0;
-    return (size_t)nslab * ((size_t)P.Cout * P.ks * P.ks * P.Cin_tot + (with_bias ? P.Cout : 0));
+    return (nslab <= 1 ? 0 : (size_t)nslab * P.Cout * P.ks * P.ks * P.Cin_tot) +
+           (with_bias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
 }

@@ -1,0 +1,258 @@
+// wgrad v2: weight gradient with a (nearly) VALU-free main loop -- see
+// gconv2.hip for why (f32 MFMA shares the vector datapath on gfx950).
+//
+//   dW[co][tap][ci] = sum_pix gout[pix][co] * Xvirt[pix @ tap][ci]
+//   GEMM rows = co, columns = flattened (tap, ci) of one VECTOR concat member
+//   (flat members keep the v1 kernel), K = output pixels in groups of 16.
+//
+// Both operands are K-major in memory, so a K slice is [16 pixels][rows] and
+// an LDS-DMA piece (1 KiB, lane-linear) is a few whole pixel rows: no swizzle,
+// fragments are read one float per lane (consecutive lanes = consecutive
+// banks) with immediate offsets.  Requires Wo % 16 == 0 so that a 16-pixel
+// group never straddles an image row: the group's base offset is then a
+// scalar (SGPR soffset), the per-lane part of the gout offset is a constant
+// and the per-lane part of the input offset needs only the column bound
+// check (left/right image border) per slice.
+#include "conv_common.h"
+
+namespace {
+constexpr int WNS = 4;  // ring stages
+constexpr unsigned WOOB = 0x80000000u;
+}  // namespace
+
+template <int WROWS, int WCOLS, int TM, int TN>
+__global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    constexpr int PA0 = BMc / 16, PB = BN / 16;     // 1 KiB pieces per slice
+    // pad the A pieces so that every wave issues the same number of LDS-DMAs
+    constexpr int PA = PA0 + ((4 - (PA0 + PB) % 4) % 4);
+    constexpr int LPW = (PA + PB) / 4;
+    constexpr int STAGE = (PA + PB) * 1024;
+    constexpr int RPA = 256 / BMc, RPB = 256 / BN;  // pixel rows per piece
+    static_assert(WROWS * WCOLS == CONV_NT / kWave, "4 waves");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int taps = P.ks * P.ks;
+
+    int s = 0;
+    for (int i = 1; i < P.nsrc; ++i)
+        if ((int)blockIdx.x >= P.tile_begin[i]) s = i;
+    const GSrc &S = P.src[s];
+    int coff = 0;
+    for (int i = 0; i < s; ++i) coff += P.src[i].C;
+    const int f0 = ((int)blockIdx.x - P.tile_begin[s]) * BN;
+    const int fmax = taps * S.C;
+    const int co0 = blockIdx.y * BMc;
+    const int ph = blockIdx.z / P.S, split = blockIdx.z - ph * P.S;
+    const int phy = ph >> 1, phx = ph & 1;
+    const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
+    const int kbeg = split * P.klen;
+    const int kend = min(P.M, kbeg + P.klen);
+    const int nsteps = (kend - kbeg + BK - 1) / BK;
+
+    // ---- per-lane constants of the load slots (piece p = wave + 4*i)
+    unsigned a_voff[LPW];          // A slots: constant;  B slots: column part
+    int b_j[LPW], b_kx[LPW], b_ky[LPW];
+    bool b_ok[LPW];
+    unsigned b_col[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int p = wave + 4 * i;
+        a_voff[i] = WOOB;
+        b_j[i] = b_kx[i] = b_ky[i] = 0;
+        b_ok[i] = false;
+        b_col[i] = 0;
+        if (p < PA) {
+            const int j = p * RPA + (lane * 4) / BMc, col = (lane * 4) % BMc;
+            if (p < PA0 && co0 + col < P.Cout)
+                a_voff[i] = (unsigned)((j * P.g_sx + co0 + col) * 4);
+        } else {
+            const int q = p - PA;
+            const int j = q * RPB + (lane * 4) / BN, col = (lane * 4) % BN;
+            const int f = f0 + col;
+            b_j[i] = j;
+            b_ok[i] = f < fmax;
+            const int tap = b_ok[i] ? f / S.C : 0, c = f - tap * S.C;
+            b_ky[i] = tap / P.ks;
+            b_kx[i] = tap - b_ky[i] * P.ks;
+            b_col[i] = (unsigned)(c * 4);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t gres =
+        __builtin_amdgcn_make_buffer_rsrc((void *)P.gout, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sres =
+        __builtin_amdgcn_make_buffer_rsrc((void *)S.p, 0, 0x7fffffff, 0x00020000);
+    const long long g_ph = (long long)phy * P.g_py + (long long)phx * P.g_px;
+
+    // 16-pixel group -> (b, oy, ox0), all scalar
+    int g_ox = 0, g_oy = 0, g_b = 0;
+    {
+        const int pix = kbeg;
+        g_ox = pix % P.Wo;
+        const int t = pix / P.Wo;
+        g_oy = t % P.Ho;
+        g_b = t / P.Ho;
+    }
+    int issued_pix = kbeg;
+
+    auto issue = [&](int stage_idx) {
+        const int a_soff = __builtin_amdgcn_readfirstlane(
+            (int)(((long long)g_b * P.g_sb + (long long)g_oy * P.g_sy + (long long)g_ox * P.g_sx + g_ph) * 4));
+        unsigned char *st = smem + stage_idx * STAGE;
+        const bool tail = issued_pix + BK > kend;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int p = wave + 4 * i;
+            __attribute__((address_space(3))) void *dst =
+                (__attribute__((address_space(3))) void *)(st + p * 1024);
+            if (p < PA) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, a_voff[i], a_soff, 0, 0);
+            } else {
+                // input pixel of (group row, lane pixel j, tap)
+                const int Y = g_oy * P.stride - pad_y + b_ky[i];       // per-lane tap row
+                const int X = (g_ox + b_j[i]) * P.stride - pad_x + b_kx[i];
+                bool ok = b_ok[i] & ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+                if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
+                if (tail) ok &= issued_pix + b_j[i] < kend;
+                const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
+                const unsigned v = (unsigned)((ys * S.sy + xs * S.sx) * 4) + b_col[i];
+                const int b_soff = __builtin_amdgcn_readfirstlane((int)((long long)g_b * S.sb * 4));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sres, dst, 16, ok ? v : WOOB, b_soff, 0, 0);
+            }
+        }
+        // next group (Wo % 16 == 0: groups do not straddle rows)
+        issued_pix += BK;
+        g_ox += BK;
+        if (g_ox >= P.Wo) {
+            g_ox = 0;
+            if (++g_oy == P.Ho) {
+                g_oy = 0;
+                ++g_b;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int a_base = (lh * BMc + wr * TM * 32 + lrow) * 4;
+    const int b_base = PA * 1024 + (lh * BN + wc * TN * 32 + lrow) * 4;
+
+    auto compute = [&](const unsigned char *stage) {
+#pragma unroll
+        for (int q = 0; q < BK / 2; ++q) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                a[t] = *(const float *)(stage + a_base + (2 * q * BMc + t * 32) * 4);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                b[t] = *(const float *)(stage + b_base + (2 * q * BN + t * 32) * 4);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int u = 0; u < WNS - 1; ++u)
+        if (u < nsteps) issue(u);
+    for (int s0 = 0; s0 < nsteps; s0 += WNS) {
+#pragma unroll
+        for (int u = 0; u < WNS; ++u) {
+            const int st = s0 + u;
+            if (st < nsteps) {
+                if (st + WNS - 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WNS - 2) * LPW) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                if (st + WNS - 1 < nsteps) issue((u + WNS - 1) % WNS);
+                compute(smem + u * STAGE);
+            }
+        }
+    }
+
+    const size_t wsize = (size_t)P.Cout * taps * P.Cin_tot;
+    float *dW = P.dW + (size_t)blockIdx.z * wsize;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int f = f0 + (wc * TN + tn) * 32 + lrow;
+        if (f >= fmax) continue;
+        const int tap = f / S.C, c = f - tap * S.C;
+        const size_t col = (size_t)tap * P.Cin_tot + coff + c;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + (wr * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (co < P.Cout) dW[(size_t)co * taps * P.Cin_tot + col] = acc[tm][tn][reg];
+            }
+    }
+#endif
+}
+
+namespace {
+
+template <int WROWS, int WCOLS, int TM, int TN>
+int launch_w2(const WGradParams &P, int ntiles, hipStream_t st)
+{
+    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    constexpr int PA0 = BMc / 16, PB = BN / 16, PA = PA0 + ((4 - (PA0 + PB) % 4) % 4);
+    constexpr size_t LDS = (size_t)WNS * (PA + PB) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad2_kernel<WROWS, WCOLS, TM, TN>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_set = true;
+    }
+    dim3 grid(ntiles, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
+    hipLaunchKernelGGL((wgrad2_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), LDS, st, P);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+}  // namespace
+
+// v2 handles the vector members when image rows are whole 16-pixel groups.
+bool wgrad2_eligible(const WGradParams &P)
+{
+    if (P.Wo % BK || P.klen % BK) return false;
+    for (int s = 0; s < P.nsrc; ++s)
+        if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return false;
+    long long bytes = (long long)P.B * P.g_sb * 4;
+    for (int s = 0; s < P.nsrc; ++s) {
+        const long long b = (long long)P.B * P.src[s].sb * 4;
+        bytes = b > bytes ? b : bytes;
+    }
+    return bytes < 0x7fffffffLL;
+}
+
+// P.tile_begin must already enumerate ONLY the vector members' column tiles
+// for the tile width of `tile`.
+int wgrad2_launch(const WGradParams &P, int tile, int ntiles, hipStream_t st)
+{
+    switch (tile) {
+    case 1: return launch_w2<2, 2, 2, 2>(P, ntiles, st);  // 128 x 128
+    case 2: return launch_w2<2, 2, 2, 1>(P, ntiles, st);  // 128 x 64
+    case 3: return launch_w2<2, 2, 1, 1>(P, ntiles, st);  // 64 x 64
+    case 4: return launch_w2<2, 2, 1, 2>(P, ntiles, st);  // 64 x 128
+    default: return launch_w2<1, 4, 1, 1>(P, ntiles, st); // 32 x 128
+    }
+}
