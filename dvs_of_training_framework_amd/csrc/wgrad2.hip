@@ -56,82 +56,79 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
     const int kend = min(P.M, kbeg + P.klen);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
 
+    // scalars used in the loop, hoisted out of the kernarg segment
+    const int Hv = P.Hv, Wv = P.Wv, Wo = P.Wo, Ho = P.Ho, stride = P.stride;
+    const int s_sy = S.sy, s_sx = S.sx;
+    const long long s_sb = S.sb, g_sb = P.g_sb;
+    const int g_sy = P.g_sy, g_sx = P.g_sx;
+
     // ---- per-lane constants of the load slots (piece p = wave + 4*i)
-    unsigned a_voff[LPW];          // A slots: constant;  B slots: column part
-    int b_j[LPW], b_kx[LPW], b_ky[LPW];
+    // input pixel of (group (b,oy,ox0), lane pixel j, tap):
+    //   Y = oy*stride + cy,  X = ox0*stride + cx,  cy = ky - pad_y, cx = j*stride + kx - pad_x
+    // offset = [b*sb + oy*stride*sy + ox0*stride*sx] (SGPR) + [ky*sy + (j*stride+kx)*sx + c]
+    // with the buffer base moved back by pad_y*sy + pad_x*sx elements, so the
+    // per-lane part is a non-negative CONSTANT; only its validity varies.
+    unsigned c_voff[LPW];
+    int b_cy[LPW], b_cx[LPW];
     bool b_ok[LPW];
-    unsigned b_col[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
         const int p = wave + 4 * i;
-        a_voff[i] = WOOB;
-        b_j[i] = b_kx[i] = b_ky[i] = 0;
+        c_voff[i] = WOOB;
+        b_cy[i] = b_cx[i] = 0;
         b_ok[i] = false;
-        b_col[i] = 0;
         if (p < PA) {
             const int j = p * RPA + (lane * 4) / BMc, col = (lane * 4) % BMc;
             if (p < PA0 && co0 + col < P.Cout)
-                a_voff[i] = (unsigned)((j * P.g_sx + co0 + col) * 4);
+                c_voff[i] = (unsigned)((j * g_sx + co0 + col) * 4);
         } else {
             const int q = p - PA;
             const int j = q * RPB + (lane * 4) / BN, col = (lane * 4) % BN;
             const int f = f0 + col;
-            b_j[i] = j;
             b_ok[i] = f < fmax;
             const int tap = b_ok[i] ? f / S.C : 0, c = f - tap * S.C;
-            b_ky[i] = tap / P.ks;
-            b_kx[i] = tap - b_ky[i] * P.ks;
-            b_col[i] = (unsigned)(c * 4);
+            const int ky = tap / P.ks, kx = tap - ky * P.ks;
+            b_cy[i] = ky - pad_y;
+            b_cx[i] = j * stride + kx - pad_x;
+            c_voff[i] = (unsigned)((ky * s_sy + (j * stride + kx) * s_sx + c) * 4);
         }
     }
     const __amdgpu_buffer_rsrc_t gres =
         __builtin_amdgcn_make_buffer_rsrc((void *)P.gout, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t sres =
-        __builtin_amdgcn_make_buffer_rsrc((void *)S.p, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(S.p - ((long long)pad_y * s_sy + (long long)pad_x * s_sx)), 0, 0x7fffffff,
+        0x00020000);
     const long long g_ph = (long long)phy * P.g_py + (long long)phx * P.g_px;
 
     // 16-pixel group -> (b, oy, ox0), all scalar
-    int g_ox = 0, g_oy = 0, g_b = 0;
-    {
-        const int pix = kbeg;
-        g_ox = pix % P.Wo;
-        const int t = pix / P.Wo;
-        g_oy = t % P.Ho;
-        g_b = t / P.Ho;
-    }
-    int issued_pix = kbeg;
+    int g_ox = kbeg % Wo, g_oy = (kbeg / Wo) % Ho, g_b = kbeg / (Wo * Ho);
 
     auto issue = [&](int stage_idx) {
         const int a_soff = __builtin_amdgcn_readfirstlane(
-            (int)(((long long)g_b * P.g_sb + (long long)g_oy * P.g_sy + (long long)g_ox * P.g_sx + g_ph) * 4));
+            (int)(((long long)g_b * g_sb + (long long)g_oy * g_sy + (long long)g_ox * g_sx + g_ph) * 4));
+        const int gy = g_oy * stride, gx = g_ox * stride;
+        const int b_soff = __builtin_amdgcn_readfirstlane(
+            (int)(((long long)g_b * s_sb + (long long)gy * s_sy + (long long)gx * s_sx) * 4));
         unsigned char *st = smem + stage_idx * STAGE;
-        const bool tail = issued_pix + BK > kend;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
             const int p = wave + 4 * i;
             __attribute__((address_space(3))) void *dst =
                 (__attribute__((address_space(3))) void *)(st + p * 1024);
             if (p < PA) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, a_voff[i], a_soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, c_voff[i], a_soff, 0, 0);
             } else {
-                // input pixel of (group row, lane pixel j, tap)
-                const int Y = g_oy * P.stride - pad_y + b_ky[i];       // per-lane tap row
-                const int X = (g_ox + b_j[i]) * P.stride - pad_x + b_kx[i];
-                bool ok = b_ok[i] & ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
-                if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
-                if (tail) ok &= issued_pix + b_j[i] < kend;
-                const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
-                const unsigned v = (unsigned)((ys * S.sy + xs * S.sx) * 4) + b_col[i];
-                const int b_soff = __builtin_amdgcn_readfirstlane((int)((long long)g_b * S.sb * 4));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(sres, dst, 16, ok ? v : WOOB, b_soff, 0, 0);
+                const bool ok = b_ok[i] & ((unsigned)(gy + b_cy[i]) < (unsigned)Hv) &
+                                ((unsigned)(gx + b_cx[i]) < (unsigned)Wv);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sres, dst, 16, ok ? c_voff[i] : WOOB, b_soff,
+                                                         0, 0);
             }
         }
         // next group (Wo % 16 == 0: groups do not straddle rows)
-        issued_pix += BK;
         g_ox += BK;
-        if (g_ox >= P.Wo) {
+        if (g_ox >= Wo) {
             g_ox = 0;
-            if (++g_oy == P.Ho) {
+            if (++g_oy == Ho) {
                 g_oy = 0;
                 ++g_b;
             }
@@ -147,47 +144,62 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lrow = lane & 31, lh = lane >> 5;
-    const int a_base = (lh * BMc + wr * TM * 32 + lrow) * 4;
-    const int b_base = PA * 1024 + (lh * BN + wc * TN * 32 + lrow) * 4;
+    // LDS byte addresses of this lane's fragment column (k parity = lh)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const unsigned a_base = lds0 + (unsigned)((lh * BMc + wr * TM * 32 + lrow) * 4);
+    const unsigned b_base = lds0 + (unsigned)(PA * 1024 + (lh * BN + wc * TN * 32 + lrow) * 4);
 
-    auto compute = [&](const unsigned char *stage) {
-#pragma unroll
-        for (int q = 0; q < BK / 2; ++q) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-                a[t] = *(const float *)(stage + a_base + (2 * q * BMc + t * 32) * 4);
-#pragma unroll
-            for (int t = 0; t < TN; ++t)
-                b[t] = *(const float *)(stage + b_base + (2 * q * BN + t * 32) * 4);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-        }
-    };
+    // Fragment reads with IMMEDIATE offsets (hipcc would fuse them into
+    // ds_read2_b32 and spend a v_add per pair).  Inline-asm loads are invisible
+    // to the compiler's waitcnt pass: lgkmcnt(0) + sched_barrier before use.
+#define DS_READ(dst, base, off) \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define W2_COMPUTE(U)                                                                          \
+    {                                                                                          \
+        float fa[BK / 2][TM], fb[BK / 2][TN];                                                  \
+        _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                     \
+        {                                                                                      \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
+                DS_READ(fa[q][t], a_base, (U) * STAGE + (2 * q * BMc + t * 32) * 4);           \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t)                                     \
+                DS_READ(fb[q][t], b_base, (U) * STAGE + (2 * q * BN + t * 32) * 4);            \
+        }                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                     \
+            _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                  \
+                _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] =                \
+                    __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][tm], fb[q][tn], acc[tm][tn], 0, \
+                                                         0, 0);                                \
+    }
+#define W2_STEP(U)                                                                          \
+    {                                                                                       \
+        const int st = s0 + (U);                                                            \
+        if (st < nsteps) {                                                                  \
+            if (st + WNS - 2 < nsteps) {                                                    \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WNS - 2) * LPW) : "memory");      \
+            } else {                                                                        \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
+            }                                                                               \
+            __builtin_amdgcn_s_barrier();                                                   \
+            if (st + WNS - 1 < nsteps) issue(((U) + WNS - 1) % WNS);                        \
+            W2_COMPUTE(U)                                                                   \
+        }                                                                                   \
+    }
 
 #pragma unroll
     for (int u = 0; u < WNS - 1; ++u)
         if (u < nsteps) issue(u);
+    static_assert(WNS == 4, "the ring below is written out for 4 stages");
     for (int s0 = 0; s0 < nsteps; s0 += WNS) {
-#pragma unroll
-        for (int u = 0; u < WNS; ++u) {
-            const int st = s0 + u;
-            if (st < nsteps) {
-                if (st + WNS - 2 < nsteps) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WNS - 2) * LPW) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();
-                if (st + WNS - 1 < nsteps) issue((u + WNS - 1) % WNS);
-                compute(smem + u * STAGE);
-            }
-        }
+        W2_STEP(0)
+        W2_STEP(1)
+        W2_STEP(2)
+        W2_STEP(3)
     }
+#undef W2_STEP
+#undef W2_COMPUTE
+#undef DS_READ
 
     const size_t wsize = (size_t)P.Cout * taps * P.Cin_tot;
     float *dW = P.dW + (size_t)blockIdx.z * wsize;
@@ -233,7 +245,7 @@ int launch_w2(const WGradParams &P, int ntiles, hipStream_t st)
 // v2 handles the vector members when image rows are whole 16-pixel groups.
 bool wgrad2_eligible(const WGradParams &P)
 {
-    if (P.Wo % BK || P.klen % BK) return false;
+    if (P.Wo % BK || P.klen % BK || P.up != UP_NONE) return false;
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return false;
     long long bytes = (long long)P.B * P.g_sb * 4;
