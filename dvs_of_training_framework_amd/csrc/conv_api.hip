@@ -5,7 +5,9 @@
 
 
 int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st);
-int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats, hipStream_t st);
+int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats,
+                 const FlatWG *flat, int nflat, hipStream_t st);
+size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat);
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias);
 int gconv_pick_tile(long long m, long long n);
 int wgrad_splits(const WGradParams &P0, int *tile_out);
@@ -362,6 +364,36 @@ void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParam
     P.dbias = nullptr;
 }
 
+int fill_flat(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, const float *gout, FlatWG *F)
+{
+    int n = 0, coff = 0;
+    const int up = d->upsample ? 2 : 1;
+    for (int i = 0; i < d->nsrc; ++i) {
+        const GSrc g = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+        if (g.flat) {
+            FlatWG &f = F[n++];
+            f.S = g;
+            f.gout = gout;
+            f.B = d->B;
+            f.Hv = d->H * up;
+            f.Wv = d->W * up;
+            f.up = d->upsample ? UP_NEAREST : UP_NONE;
+            f.Ho = Ho;
+            f.Wo = Wo;
+            f.stride = d->stride;
+            f.pad = d->pad;
+            f.ks = d->ksize;
+            f.Cout = d->Cout;
+            f.M = d->B * Ho * Wo;
+            f.ncol = d->ksize * d->ksize * g.C;
+            f.coff = coff;
+            f.Cin_tot = Ctot;
+        }
+        coff += d->src[i].C;
+    }
+    return n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -513,7 +545,9 @@ size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
-    return wgrad_workspace_floats(P, true) * sizeof(float) + 16;
+    FlatWG F[3];
+    const int nflat = fill_flat(d, Ctot, Ho, Wo, nullptr, F);
+    return (wgrad_workspace_floats(P, true) + wgrad_flat_workspace_floats(F, nflat)) * sizeof(float) + 16;
 }
 
 int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dweight, float *dbias,
@@ -524,8 +558,12 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
     P.gout = gout;
-    if (wgrad_workspace_floats(P, dbias != nullptr) > 0 && !ws) return DVSOF_ENOSPACE;
-    return wgrad_launch(P, dweight, dbias, (float *)ws, ws_bytes / sizeof(float), as_stream(stream));
+    FlatWG F[3];
+    const int nflat = fill_flat(d, Ctot, Ho, Wo, gout, F);
+    if (wgrad_workspace_floats(P, dbias != nullptr) + wgrad_flat_workspace_floats(F, nflat) > 0 && !ws)
+        return DVSOF_ENOSPACE;
+    return wgrad_launch(P, dweight, dbias, (float *)ws, ws_bytes / sizeof(float), F, nflat,
+                        as_stream(stream));
 }
 
 size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *d)

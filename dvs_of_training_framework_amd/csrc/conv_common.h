@@ -75,6 +75,15 @@ struct WGradParams {
     int nph, ph_pad, S;   // phases (1|4), pad shift per phase, K splits
 };
 
+// Weight gradient of one flat concat member on the VALU (wgrad.hip), in the
+// layer's ORIGINAL geometry (3x3 taps on the nearest-upsampled input).
+struct FlatWG {
+    GSrc S;
+    const float *gout;   // dense [B*Ho*Wo][Cout]
+    int B, Hv, Wv, up, Ho, Wo, stride, pad, ks, Cout, M, ncol;
+    int coff, Cin_tot;   // column offset / total channels of the layer weight
+};
+
 __device__ __forceinline__ float act_fwd(float v, int act)
 {
     if (act == ACT_RELU) return fmaxf(v, 0.f);

@@ -16,6 +16,7 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat);
 bool wgrad2_eligible(const WGradParams &P);
 int wgrad2_launch(const WGradParams &P, int tile, int ntiles, hipStream_t st);
 
@@ -247,20 +248,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g
     }
 }
 
-// out[i] = sum_z slab[z][i], fixed order
+// out[i] = sum_z slab[z][i], fixed order; four slabs in flight per thread
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab,
                                                           float *__restrict__ out, size_t n, int S)
 {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 3 < n) {
-        f32x4 a = *(const f32x4u *)(slab + i);
-        for (int z = 1; z < S; ++z) a += *(const f32x4u *)(slab + (size_t)z * n + i);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 3 < S; z += 4) {
+            const f32x4 v0 = *(const f32x4u *)(slab + (size_t)z * n + i);
+            const f32x4 v1 = *(const f32x4u *)(slab + (size_t)(z + 1) * n + i);
+            const f32x4 v2 = *(const f32x4u *)(slab + (size_t)(z + 2) * n + i);
+            const f32x4 v3 = *(const f32x4u *)(slab + (size_t)(z + 3) * n + i);
+            a = (((a + v0) + v1) + v2) + v3;
+        }
+        for (; z < S; ++z) a += *(const f32x4u *)(slab + (size_t)z * n + i);
         *(f32x4u *)(out + i) = a;
     } else {
         for (size_t j = i; j < n; ++j) {
-            float a = slab[j];
-            for (int z = 1; z < S; ++z) a += slab[(size_t)z * n + j];
+            float a = 0.f;
+            for (int z = 0; z < S; ++z) a += slab[(size_t)z * n + j];
             out[j] = a;
         }
     }
@@ -294,6 +303,119 @@ __global__ __launch_bounds__(256) void subpixel_fold_kernel(const float *__restr
             for (int z = 0; z < S; ++z) acc += sl[(size_t)z * wsize];
         }
     dW[i] = acc;
+}
+
+// ---- weight gradient of "flat" concat members (2-channel flow, 5-bin voxel
+// grid) on the VALU: dW[co][tap][c] = sum_pix gout[pix][co] * Xvirt[pix@tap][c]
+// straight from the layer definition (nearest-upsampled virtual input), so it
+// needs neither the sub-pixel phases nor the MFMA tiles (an MFMA column tile
+// for 8..45 columns would run the whole K loop at <10 % utilisation).
+// HBM-bound: reads gout once.  part[block][co][NCOL], then a fixed-order sum.
+constexpr int FLAT_BLOCKS = 512;
+constexpr int FLAT_PIX = 64;   // pixels staged per round
+
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *__restrict__ part)
+{
+    __shared__ float xs[FLAT_PIX][NCOL + 1];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int G = P.Cout < 256 ? P.Cout : 256;      // channel lanes
+    const int RP = 256 / G;                         // pixel lanes
+    const int cl = tid % G, pl = tid / G;
+    const long long per = ((long long)P.M + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * per;
+    const long long p1 = p0 + per < P.M ? p0 + per : P.M;
+    for (int cbase = 0; cbase < P.Cout; cbase += G) {
+        float acc[NCOL];
+#pragma unroll
+        for (int i = 0; i < NCOL; ++i) acc[i] = 0.f;
+        for (long long base = p0; base < p1; base += FLAT_PIX) {
+            __syncthreads();
+            for (int e = tid; e < FLAT_PIX * NCOL; e += 256) {
+                const int p = e / NCOL, col = e - p * NCOL;
+                const long long pix = base + p;
+                float v = 0.f;
+                if (pix < p1) {
+                    const int ox = (int)(pix % P.Wo);
+                    const long long t = pix / P.Wo;
+                    const int oy = (int)(t % P.Ho), b = (int)(t / P.Ho);
+                    const int tap = col / P.S.C, c = col - tap * P.S.C;
+                    const int ky = tap / P.ks, kx = tap - ky * P.ks;
+                    const int Y = oy * P.stride - P.pad + ky, X = ox * P.stride - P.pad + kx;
+                    if ((unsigned)Y < (unsigned)P.Hv && (unsigned)X < (unsigned)P.Wv) {
+                        const int ys = P.up ? Y >> 1 : Y, xsrc = P.up ? X >> 1 : X;
+                        v = P.S.p[(size_t)b * P.S.sb + (size_t)ys * P.S.sy + (size_t)xsrc * P.S.sx +
+                                  (size_t)c * P.S.sc];
+                    }
+                }
+                xs[p][col] = v;
+            }
+            __syncthreads();
+            if (pl < RP && cbase + cl < P.Cout) {
+                const int np = (int)((p1 - base) < FLAT_PIX ? (p1 - base) : FLAT_PIX);
+                for (int p = pl; p < np; p += RP) {
+                    const float g = P.gout[(size_t)(base + p) * P.Cout + cbase + cl];
+#pragma unroll
+                    for (int i = 0; i < NCOL; ++i) acc[i] = fmaf(g, xs[p][i], acc[i]);
+                }
+            }
+        }
+        // sum the pixel lanes, one column at a time
+#pragma unroll 1
+        for (int i = 0; i < NCOL; ++i) {
+            __syncthreads();
+            red[tid] = acc[i];
+            __syncthreads();
+            if (tid < G && cbase + tid < P.Cout) {
+                float t = 0.f;
+                for (int k = 0; k < RP; ++k) t += red[k * G + tid];
+                part[((size_t)blockIdx.x * P.Cout + cbase + tid) * NCOL + i] = t;
+            }
+        }
+    }
+}
+
+// dW[co][tap][coff + c] = sum_blocks part[blk][co][tap*C + c]
+__global__ __launch_bounds__(256) void wgrad_flat_reduce_kernel(const float *__restrict__ part,
+                                                                int nblocks, int Cout, int ncol,
+                                                                int C, int coff, int row_stride,
+                                                                int tap_stride, float *dW)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * ncol) return;
+    const int co = i / ncol, col = i - co * ncol;
+    float a = 0.f;
+    for (int b = 0; b < nblocks; ++b) a += part[(size_t)b * Cout * ncol + i];
+    const int tap = col / C, c = col - tap * C;
+    dW[(size_t)co * row_stride + (size_t)tap * tap_stride + coff + c] = a;
+}
+
+bool flat_ncol_ok(int ncol)
+{
+    return ncol == 18 || ncol == 27 || ncol == 45 || ncol == 81 || ncol == 108;
+}
+
+int flat_launch(const FlatWG &F, float *part, float *dW, hipStream_t st)
+{
+    const long long nbl = ((long long)F.M + FLAT_PIX - 1) / FLAT_PIX;
+    const int nb = (int)(nbl < FLAT_BLOCKS ? (nbl < 1 ? 1 : nbl) : FLAT_BLOCKS);
+    switch (F.ncol) {
+    case 18: hipLaunchKernelGGL(wgrad_flat_kernel<18>, dim3(nb), dim3(256), 0, st, F, part); break;
+    case 27: hipLaunchKernelGGL(wgrad_flat_kernel<27>, dim3(nb), dim3(256), 0, st, F, part); break;
+    case 45: hipLaunchKernelGGL(wgrad_flat_kernel<45>, dim3(nb), dim3(256), 0, st, F, part); break;
+    case 81: hipLaunchKernelGGL(wgrad_flat_kernel<81>, dim3(nb), dim3(256), 0, st, F, part); break;
+    case 108: hipLaunchKernelGGL(wgrad_flat_kernel<108>, dim3(nb), dim3(256), 0, st, F, part); break;
+    default: return DVSOF_EINVAL;
+    }
+    DVSOF_LAUNCH_CHECK();
+    const int taps = F.ks * F.ks;
+    hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3((F.Cout * F.ncol + 255) / 256), dim3(256), 0,
+                       st, (const float *)part, nb, F.Cout, F.ncol, F.S.C, F.coff,
+                       taps * F.Cin_tot, F.Cin_tot, dW);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
 }
 
 // column tiles of the members selected by `want_flat` (others get none)
@@ -333,11 +455,45 @@ void tile_dims(int tile, int &bm, int &bn)
     }
 }
 
-int pick_tile(const WGradParams &P)
+// (tile, K splits): the largest tile that reaches >= 512 workgroups (2 per CU)
+// with at most 2 K splits; K splits cost a slab write + read of |dW| each.
+int pick_tile_and_splits(const WGradParams &P, int *S_out)
 {
-    if (P.Cout <= 32) return 5;
-    if (P.Cout <= 64) return 4;
-    return 1;
+    const int taps = P.ks * P.ks;
+    static const int cand[5] = {1, 4, 3, 5, 2};   // by preference
+    int best = -1, bestS = 1;
+    double best_cost = 1e300;
+    for (int i = 0; i < 5; ++i) {
+        int bm, bn;
+        tile_dims(cand[i], bm, bn);
+        if (bm > 32 && bm / 2 >= P.Cout) continue;      // mostly padding rows
+        long long tiles = 0;
+        for (int s = 0; s < P.nsrc; ++s)
+            if (!P.src[s].flat) tiles += (taps * P.src[s].C + bn - 1) / bn;
+        if (tiles == 0)
+            for (int s = 0; s < P.nsrc; ++s) tiles += (taps * P.src[s].C + bn - 1) / bn;
+        const long long rows = (P.Cout + bm - 1) / bm;
+        tiles *= rows * P.nph;
+        int S = (int)((512 + tiles - 1) / tiles);
+        const int maxS = (P.M + 511) / 512;              // >= 32 K slices per split
+        if (S > maxS) S = maxS;
+        if (S < 1) S = 1;
+        if (S > 64) S = 64;
+        // cost model: padded MFMA work / tile efficiency + slab traffic
+        const double eff = (bm * bn >= 128 * 128) ? 1.0 : (bm * bn >= 64 * 128) ? 0.85 : 0.7;
+        double work = (double)tiles * bm * bn * P.M / eff;              // MACs
+        const double blocks = (double)tiles * S;
+        if (blocks < 512) work *= 512.0 / blocks;
+        const double slab = (S * P.nph > 1) ? 2.0 * S * P.nph * P.Cout * taps * P.Cin_tot * 4.0 : 0.0;
+        const double cost = work / 70e12 * 2.0 + slab / 3e12;           // seconds (rough)
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = cand[i];
+            bestS = S;
+        }
+    }
+    if (S_out) *S_out = bestS;
+    return best;
 }
 
 }  // namespace
@@ -345,27 +501,16 @@ int pick_tile(const WGradParams &P)
 // Number of K splits used for this problem (deterministic in the shape).
 int wgrad_splits(const WGradParams &P0, int *tile_out)
 {
-    const int tile = pick_tile(P0);
-    int bm, bn;
-    tile_dims(tile, bm, bn);
-    const int taps = P0.ks * P0.ks;
-    long long tiles = 0;
-    for (int s = 0; s < P0.nsrc; ++s) tiles += (taps * P0.src[s].C + bn - 1) / bn;
-    tiles *= (P0.Cout + bm - 1) / bm;
-    tiles *= P0.nph;
-    // aim at >= 1024 workgroups, at least 8 K slices (128 pixels) per split
-    int S = (int)((1024 + tiles - 1) / tiles);
-    const int maxS = (P0.M + 127) / 128;
-    if (S > maxS) S = maxS;
-    if (S < 1) S = 1;
-    if (S > 256) S = 256;
+    int S = 1;
+    const int tile = pick_tile_and_splits(P0, &S);
     if (tile_out) *tile_out = tile;
     return S;
 }
 
 // Internal entry: ws holds the nph*S slabs when needed, results go to dW/dbias.
 // In phase mode (nph = 4) dW is the folded [Cout][3][3][Cin_tot] gradient.
-int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats, hipStream_t st)
+int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_floats,
+                 const FlatWG *flat, int nflat, hipStream_t st)
 {
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
@@ -377,12 +522,17 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
     const bool direct = nslab == 1;
     const size_t need = (direct ? 0 : (size_t)nslab * wsize) +
                         (dbias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
-    if (need > ws_floats) return DVSOF_ENOSPACE;
+    if (need + wgrad_flat_workspace_floats(flat, nflat) > ws_floats) return DVSOF_ENOSPACE;
     P.klen = (((P.M + S - 1) / S) + BK - 1) / BK * BK;
     P.dW = direct ? dW : ws;
     P.dbias = nullptr;   // bias gradient: separate column-sum pass below
     static const bool force_v1 = getenv("DVSOF_WGRAD_V1") != nullptr;
-    int want_flat = -1;  // v1 for everything ...
+    // flat members: dedicated VALU kernel when every one of them qualifies
+    bool flat_valu = nflat > 0 && !force_v1;
+    for (int i = 0; i < nflat; ++i) flat_valu = flat_valu && flat_ncol_ok(flat[i].ncol);
+    bool any_vec = false;
+    for (int s = 0; s < P.nsrc; ++s) any_vec = any_vec || !P.src[s].flat;
+    int want_flat = -1;  // v1 MFMA tiles for everything ...
     int rc = DVSOF_OK;
     if (!force_v1 && wgrad2_eligible(P)) {  // ... or v2 for the vector members
         int bm, bn;
@@ -391,15 +541,20 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
         if (nt > 0) rc = wgrad2_launch(P, tile, nt, st);
         if (rc) return rc;
         want_flat = 1;
+    } else if (flat_valu) {
+        want_flat = 0;   // v1 for the vector members only
     }
-    switch (tile) {
-    case 1: rc = launch<2, 2, 2, 2>(P, want_flat, st); break;
-    case 2: rc = launch<2, 2, 2, 1>(P, want_flat, st); break;
-    case 3: rc = launch<2, 2, 1, 1>(P, want_flat, st); break;
-    case 4: rc = launch<2, 2, 1, 2>(P, want_flat, st); break;
-    default: rc = launch<1, 4, 1, 1>(P, want_flat, st); break;
+    const bool run_v1 = !(want_flat == 1 && (flat_valu || nflat == 0)) && (want_flat != 0 || any_vec);
+    if (run_v1) {
+        switch (tile) {
+        case 1: rc = launch<2, 2, 2, 2>(P, want_flat, st); break;
+        case 2: rc = launch<2, 2, 2, 1>(P, want_flat, st); break;
+        case 3: rc = launch<2, 2, 1, 1>(P, want_flat, st); break;
+        case 4: rc = launch<2, 2, 1, 2>(P, want_flat, st); break;
+        default: rc = launch<1, 4, 1, 1>(P, want_flat, st); break;
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
     if (dbias) {  // column sums of gout (all phases cover gout exactly once)
         const long long rows = (long long)P.B * (P.g_sb / P.Cout);
         float *part = ws + (direct ? 0 : (size_t)nslab * wsize);
@@ -410,7 +565,7 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
                            0, st, (const float *)part, dbias, (size_t)P.Cout, nb);
         DVSOF_LAUNCH_CHECK();
     }
-    if (!direct) {
+    if (!direct && (any_vec || !flat_valu)) {
         if (P.nph == 4) {
             const size_t n = (size_t)P.Cout * 9 * P.Cin_tot;
             hipLaunchKernelGGL(subpixel_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -421,7 +576,23 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
         }
         DVSOF_LAUNCH_CHECK();
     }
+    if (flat_valu) {   // overwrites the flat members' columns of dW
+        float *part = ws + (direct ? 0 : (size_t)nslab * wsize) +
+                      (dbias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
+        for (int i = 0; i < nflat; ++i) {
+            rc = flat_launch(flat[i], part, dW, st);
+            if (rc) return rc;
+            part += (size_t)FLAT_BLOCKS * flat[i].Cout * flat[i].ncol;
+        }
+    }
     return DVSOF_OK;
+}
+
+size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat)
+{
+    size_t n = 0;
+    for (int i = 0; i < nflat; ++i) n += (size_t)FLAT_BLOCKS * flat[i].Cout * flat[i].ncol;
+    return n;
 }
 
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias)
