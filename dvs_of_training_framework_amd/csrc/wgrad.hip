@@ -362,8 +362,9 @@ __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *
                 }
             }
         }
-        // sum the pixel lanes, one column at a time
-#pragma unroll 1
+        // sum the pixel lanes, one column at a time (static indices: a
+        // runtime-indexed acc[] would live in scratch memory)
+#pragma unroll
         for (int i = 0; i < NCOL; ++i) {
             __syncthreads();
             red[tid] = acc[i];
@@ -377,19 +378,23 @@ __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *
     }
 }
 
-// dW[co][tap][coff + c] = sum_blocks part[blk][co][tap*C + c]
+// dW[co][tap][coff + c] = sum_blocks part[blk][co][tap*C + c]; one wave per
+// output, lanes stride over the workgroups, shuffle tree (fixed order)
 __global__ __launch_bounds__(256) void wgrad_flat_reduce_kernel(const float *__restrict__ part,
                                                                 int nblocks, int Cout, int ncol,
                                                                 int C, int coff, int row_stride,
                                                                 int tap_stride, float *dW)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= Cout * ncol) return;
     const int co = i / ncol, col = i - co * ncol;
     float a = 0.f;
-    for (int b = 0; b < nblocks; ++b) a += part[(size_t)b * Cout * ncol + i];
-    const int tap = col / C, c = col - tap * C;
-    dW[(size_t)co * row_stride + (size_t)tap * tap_stride + coff + c] = a;
+    for (int b = lane; b < nblocks; b += 64) a += part[(size_t)b * Cout * ncol + i];
+    a = wave_sum(a);
+    if (lane == 0) {
+        const int tap = col / C, c = col - tap * C;
+        dW[(size_t)co * row_stride + (size_t)tap * tap_stride + coff + c] = a;
+    }
 }
 
 bool flat_ncol_ok(int ncol)
@@ -411,7 +416,7 @@ int flat_launch(const FlatWG &F, float *part, float *dW, hipStream_t st)
     }
     DVSOF_LAUNCH_CHECK();
     const int taps = F.ks * F.ks;
-    hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3((F.Cout * F.ncol + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3((F.Cout * F.ncol + 3) / 4), dim3(256), 0,
                        st, (const float *)part, nb, F.Cout, F.ncol, F.S.C, F.coff,
                        taps * F.Cin_tot, F.Cin_tot, dW);
     DVSOF_LAUNCH_CHECK();
