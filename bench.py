@@ -30,14 +30,19 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-TILE_NAMES = {
-    'gconv': {1: 'gconv_kernel<2,2,2,2> 128x128', 2: 'gconv_kernel<2,2,2,1> 128x64',
-              3: 'gconv_kernel<2,2,1,1> 64x64', 4: 'gconv_kernel<4,1,2,1> 256x32',
-              5: 'gconv_kernel<4,1,1,1> 128x32'},
-    'wgrad': {1: 'wgrad_kernel<2,2,2,2> 128x128', 2: 'wgrad_kernel<2,2,2,1> 128x64',
-              3: 'wgrad_kernel<2,2,1,1> 64x64', 4: 'wgrad_kernel<2,2,1,2> 64x128',
-              5: 'wgrad_kernel<1,4,1,1> 32x128'},
+TILE_SHAPES = {
+    'gconv': {1: '<2,2,2,2> 128x128', 2: '<2,2,2,1> 128x64', 3: '<2,2,1,1> 64x64',
+              4: '<4,1,2,1> 256x32', 5: '<4,1,1,1> 128x32'},
+    'wgrad': {1: '<2,2,2,2> 128x128', 2: '<2,2,2,1> 128x64', 3: '<2,2,1,1> 64x64',
+              4: '<2,2,1,2> 64x128', 5: '<1,4,1,1> 32x128'},
 }
+
+
+def kernel_name(family, tile, gen):
+    """Name as rocprofv3 reports it (kernel template + tile shape)."""
+    if gen == 0:
+        return 'wgrad_flat_kernel (VALU, flat members)'
+    return f"{family}{'2' if gen == 2 else ''}_kernel{TILE_SHAPES[family][tile]}"
 
 
 def parse():
@@ -106,6 +111,19 @@ def conv_flops(desc, kind):
     return 2.0 * desc.B * ho * wo * desc.Cout * ctot * desc.ksize ** 2
 
 
+def executed_flops(desc, kind):
+    """FLOPs the MFMA kernels actually issue: the sub-pixel decomposition of
+    upsample+3x3 runs 16 instead of 36 tap-products; the phased stride-2 data
+    gradient runs 16 (4 of them on zero weights) instead of 9."""
+    f = conv_flops(desc, kind)
+    if desc.upsample and desc.ksize == 3 and desc.pad == 1:
+        return f * 16.0 / 36.0
+    if kind == 1 and desc.stride == 2 and desc.ksize == 3 and not desc.upsample \
+            and desc.H % 2 == 0 and desc.W % 2 == 0:
+        return f * 16.0 / 9.0
+    return f
+
+
 def measure_roofline(h, steps=3):
     """Per-launch HIP-event timing of every conv-stack launch on torch's
     current stream (= the launch stream); groups by kernel template."""
@@ -118,13 +136,14 @@ def measure_roofline(h, steps=3):
         def inner(desc, *args, **kw):
             import ctypes
             tile = lib.dvsof_conv2d_tile_id(ctypes.byref(desc), kind)
+            gen = lib.dvsof_conv2d_kernel_generation(ctypes.byref(desc), kind)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(desc, *args, **kw)
             e1.record()
-            records.append((TILE_NAMES[family][tile], conv_flops(desc, kind),
-                            e0, e1))
+            records.append((kernel_name(family, tile, gen), conv_flops(desc, kind),
+                            e0, e1, executed_flops(desc, kind)))
             return out
         return inner
     C.conv_fwd = wrap(orig[0], 0, 'gconv')
@@ -137,18 +156,21 @@ def measure_roofline(h, steps=3):
     finally:
         C.conv_fwd, C.conv_dgrad, C.conv_wgrad = orig
     agg = {}
-    for name, fl, e0, e1 in records:
-        d = agg.setdefault(name, [0, 0.0, 0.0])
+    for name, fl, e0, e1, xfl in records:
+        d = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += fl
         d[2] += e0.elapsed_time(e1) * 1e-3
+        d[3] += xfl
     table = {k: dict(launches=v[0] // steps, gflop_per_step=v[1] / steps / 1e9,
                      ms_per_step=v[2] / steps * 1e3,
-                     tflops=v[1] / v[2] / 1e12) for k, v in agg.items()}
+                     tflops=v[1] / v[2] / 1e12,
+                     executed_tflops=v[3] / v[2] / 1e12) for k, v in agg.items()}
     dom = max(agg, key=lambda k: agg[k][2])
-    n, fl, sec = agg[dom]
+    n, fl, sec, xfl = agg[dom]
     total_fl = sum(v[1] for v in agg.values())
     total_s = sum(v[2] for v in agg.values())
+    total_x = sum(v[3] for v in agg.values())
     roof = {'bound': 'mfma', 'kernel': dom,
             'achieved': round(fl / sec / 1e12, 2),
             'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
@@ -156,6 +178,11 @@ def measure_roofline(h, steps=3):
             'traffic': None,
             'avg_launch_us': round(sec / n * 1e6, 2),
             'gflop_per_launch': round(fl / n / 1e9, 3),
+            # FLOPs actually issued to the matrix cores (sub-pixel / phased
+            # decompositions change the count): the hardware-utilisation view
+            'executed_tflops': round(xfl / sec / 1e12, 2),
+            'executed_frac': round(xfl / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+            'conv_stack_executed_tflops': round(total_x / total_s / 1e12, 2),
             'conv_stack_tflops': round(total_fl / total_s / 1e12, 2),
             'conv_stack_frac': round(total_fl / total_s / 1e12 /
                                      PEAK_F32_MATRIX_TFLOPS, 4),

@@ -618,6 +618,28 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
     return DVSOF_OK;
 }
 
+int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind);
+
+// 2 when the LDS-DMA (v2) kernel serves this problem's vector members, else 1
+int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *d, int kind)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo)) return DVSOF_EINVAL;
+    if (kind == 2) {
+        for (int i = 0; i < d->nsrc; ++i) {
+            const GSrc g = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+            if (!g.flat) return (Wo % BK == 0 && (!d->upsample || is_subpixel(d))) ? 2 : 1;
+        }
+        return 0;   // flat members only: VALU kernel
+    }
+    if (kind == 1) return (d->Cout % BK == 0) ? 2 : 1;
+    for (int i = 0; i < d->nsrc; ++i) {
+        const GSrc g = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+        if (!g.flat) return (g.C % BK == 0) ? 2 : 1;
+    }
+    return 1;
+}
+
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)
 {
     int Ctot, Ho, Wo;

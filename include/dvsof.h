@@ -224,6 +224,9 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *desc, const float *gout,
  * tile id (1..5: 128x128, 128x64, 64x64, 256x32|64x128, 128x32|32x128) or <0.
  */
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *desc, int kind);
+/* kernel generation serving the problem: 2 = LDS-DMA ring (gconv2/wgrad2),
+ * 1 = register-staged (gconv/wgrad), 0 = VALU-only (flat members). */
+int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *desc, int kind);
 
 /* wt[ci][k*k-1-tap][co] = w[co][tap][ci] */
 int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize,
