@@ -106,30 +106,47 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int tx = tid & (TW - 1), tr = tid >> 6;
     const int x = tx0 + tx;
+    constexpr int NP = TH / 4;   // pixels per thread (rows tr, tr+4, ...)
+    // phase A: addresses and ALL gathers of the thread's pixels first, so the
+    // 5*NP loads are in flight together instead of NP dependent round trips
+    bool valid[NP], oobv[NP];
+    float uu[NP], vv[NP], axv[NP], ayv[NP], nwv[NP], nev[NP], swv[NP], sev[NP], prv[NP];
 #pragma unroll
-    for (int j = 0; j < TH / 4; ++j) {
+    for (int j = 0; j < NP; ++j) {
         const int ly = tr + 4 * j, y = ty0 + ly;
-        if (y >= h || x >= w) continue;
+        valid[j] = (y < h) & (x < w);
         const float u = sF[0][ly + 1][tx + 1], v = sF[1][ly + 1][tx + 1];
+        uu[j] = u;
+        vv[j] = v;
         float gx, gy;
         warp_grid(S, x, y, u, v, gx, gy);
-        const bool oob = out_of_border(gx, gy);
-
+        oobv[j] = out_of_border(gx, gy);
         // grid_sample(bilinear, zeros, align_corners=True): utils/loss.py:70
         const float ix = (gx + 1.f) * S.half_w, iy = (gy + 1.f) * S.half_h;
         const float fx0 = floorf(ix), fy0 = floorf(iy);
-        const float ax = ix - fx0, ay = iy - fy0, cx = 1.f - ax, cy = 1.f - ay;
+        axv[j] = ix - fx0;
+        ayv[j] = iy - fy0;
         const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f);
         const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
         const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x0 + 1 >= 0) & (x0 + 1 < w);
         const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y0 + 1 >= 0) & (y0 + 1 < h);
         const float *r0 = I1 + (ptrdiff_t)y0 * w + x0;
-        const float nw = (vy0 & vx0) ? r0[0] : 0.f;
-        const float ne = (vy0 & vx1) ? r0[1] : 0.f;
-        const float sw = (vy1 & vx0) ? r0[w] : 0.f;
-        const float se = (vy1 & vx1) ? r0[w + 1] : 0.f;
+        nwv[j] = (valid[j] & vy0 & vx0) ? r0[0] : 0.f;
+        nev[j] = (valid[j] & vy0 & vx1) ? r0[1] : 0.f;
+        swv[j] = (valid[j] & vy1 & vx0) ? r0[w] : 0.f;
+        sev[j] = (valid[j] & vy1 & vx1) ? r0[w + 1] : 0.f;
+        prv[j] = valid[j] ? I0[(size_t)y * w + x] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int ly = tr + 4 * j, y = ty0 + ly;
+        if (!valid[j]) continue;
+        const float u = uu[j], v = vv[j];
+        const bool oob = oobv[j];
+        const float ax = axv[j], ay = ayv[j], cx = 1.f - ax, cy = 1.f - ay;
+        const float nw = nwv[j], ne = nev[j], sw = swv[j], se = sev[j];
         const float warped = nw * cx * cy + ne * ax * cy + sw * cx * ay + se * ax * ay;
-        const Charb ph = charbonnier(warped - I0[(size_t)y * w + x]);
+        const Charb ph = charbonnier(warped - prv[j]);
 
         float gu = 0.f, gv = 0.f;
         if (FWD) acc[0] += ph.val;
@@ -242,49 +259,63 @@ __global__ __launch_bounds__(NT) void loss_count_oob_kernel(const Params P)
     }
 }
 
-__device__ __forceinline__ double block_sum(double v, double *sh)
-{
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & (kWave - 1)) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-// One workgroup adds the per-tile records in a fixed order (double) and
-// applies the reference's normalisers.  terms[t*K + k], t = smooth/photo/border.
+// One workgroup adds the per-tile records in a fixed order (double) and applies
+// the reference's normalisers.  terms[t*K + k], t = smooth/photo/border.
+// Work items (scale k, sample n) and (scale k, sum i) are dealt to the 4 waves;
+// each is a lane-strided sum + shuffle tree, so there are only two barriers.
 __global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, float *terms,
                                                            float *loss_out, float w0,
                                                            float w1, float w2,
                                                            float loss_scale, int write_oob)
 {
-    __shared__ double sh[NT / kWave];
-    const int tid = threadIdx.x;
-    double total[3] = {0, 0, 0};
-    for (int k = 0; k < P.K; ++k) {
+    __shared__ double s_sum[DVSOF_MAX_SCALES][5];
+    __shared__ double s_border[DVSOF_MAX_SCALES][64];   // per (scale, sample slot)
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    constexpr int NW = NT / kWave;
+    // (k, i): global sums of photo and the four smoothness directions
+    for (int item = wave; item < P.K * 5; item += NW) {
+        const int k = item / 5, i = item - 5 * k;
         const ScaleDev &S = P.s[k];
         const float *part = P.partials + (size_t)S.block_begin * NPART;
         const int nb = P.N * S.tiles_per_sample;
-        double a[5] = {0, 0, 0, 0, 0};
-        for (int b = tid; b < nb; b += NT)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) a[i] += (double)part[(size_t)b * NPART + i];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) a[i] = block_sum(a[i], sh);
-        double border = 0;
-        for (int n = 0; n < P.N; ++n) {
-            double bs = 0, c = 0;
-            for (int b = tid; b < S.tiles_per_sample; b += NT) {
-                const float *p = part + ((size_t)n * S.tiles_per_sample + b) * NPART;
-                bs += (double)p[5];
-                c += (double)p[6];
-            }
-            bs = block_sum(bs, sh);
-            c = block_sum(c, sh);
-            if (c > 0) border += bs / (2.0 * c * (double)P.N);  // utils/loss.py:101,113
-            if (write_oob && tid == 0) P.oob[k * P.N + n] = (int)c;
+        double a = 0;
+        for (int b = lane; b < nb; b += kWave) a += (double)part[(size_t)b * NPART + i];
+        a = wave_sum(a);
+        if (lane == 0) s_sum[k][i] = a;
+    }
+    // (k, n): border sum / count of one sample; partial border per wave slot
+    for (int k = 0; k < P.K; ++k)
+        if (tid < 64) s_border[k][tid] = 0;
+    __syncthreads();
+    // sample n belongs to wave n % NW (64 % NW == 0: every slot n & 63 has one
+    // owner wave, which visits its samples in increasing n)
+    for (int item = 0; item < P.K * ((P.N + NW - 1) / NW); ++item) {
+        const int k = item % P.K, n = (item / P.K) * NW + wave;
+        if (n >= P.N) continue;
+        const ScaleDev &S = P.s[k];
+        const float *part = P.partials + ((size_t)S.block_begin + (size_t)n * S.tiles_per_sample) * NPART;
+        double bs = 0, c = 0;
+        for (int b = lane; b < S.tiles_per_sample; b += kWave) {
+            bs += (double)part[(size_t)b * NPART + 5];
+            c += (double)part[(size_t)b * NPART + 6];
         }
-        if (tid == 0) {
+        bs = wave_sum(bs);
+        c = wave_sum(c);
+        if (lane == 0) {
+            // utils/loss.py:101,113 -- samples are visited in increasing n by
+            // the same wave slot, so the accumulation order is fixed
+            if (c > 0) s_border[k][n & 63] += bs / (2.0 * c * (double)P.N);
+            if (write_oob) P.oob[k * P.N + n] = (int)c;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double total[3] = {0, 0, 0};
+        for (int k = 0; k < P.K; ++k) {
+            const ScaleDev &S = P.s[k];
+            const double *a = s_sum[k];
+            double border = 0;
+            for (int n = 0; n < 64; ++n) border += s_border[k][n];
             // empty crops contribute 0 (utils/loss.py:29-30)
             const double sm = ((S.c_smooth[0] > 0 ? a[1] / S.c_smooth[0] : 0) +
                                (S.c_smooth[1] > 0 ? a[2] / S.c_smooth[1] : 0) +
@@ -297,10 +328,10 @@ __global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, float
             total[1] += ph;
             total[2] += border;
         }
+        if (loss_out)  // combined_loss, utils/training.py:23
+            loss_out[0] = (float)((w0 * total[0] + w1 * total[1] + w2 * total[2]) /
+                                  (double)P.K * (double)loss_scale);
     }
-    if (tid == 0 && loss_out)  // combined_loss, utils/training.py:23
-        loss_out[0] = (float)((w0 * total[0] + w1 * total[1] + w2 * total[2]) /
-                              (double)P.K * (double)loss_scale);
 }
 
 // F.interpolate(bilinear, align_corners=True), utils/loss.py:20-21.
