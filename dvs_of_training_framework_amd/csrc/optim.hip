@@ -109,3 +109,135 @@ int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes, const int32_t *
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// RAdam (Liu et al., ICLR 2020) and Ranger (= RAdam + Lookahead k, alpha
+// [+ gradient centralisation]).  Replace RAdam.radam.RAdam and ranger.Ranger
+// as constructed at train_flownet.py:62-71 (un-vendored submodules upstream:
+// arithmetic restated from the published algorithms, oracle/ref_optim.py).
+// ---------------------------------------------------------------------------
+namespace {
+
+struct RAdamArgs {
+    float lr, beta1, beta2, eps, weight_decay;
+    float step_size;   // already divided by (1 - beta1^t)
+    int rectified;     // N_sma above the threshold: adaptive step
+    int lookahead;     // Ranger: this is a k-th step
+    float la_alpha;
+};
+
+__device__ __forceinline__ void radam_elem(float &p, float g, float &m, float &v, float &slow,
+                                           const RAdamArgs &a)
+{
+    v = v * a.beta2 + (1.f - a.beta2) * g * g;
+    m = m * a.beta1 + (1.f - a.beta1) * g;
+    if (a.weight_decay != 0.f) p = p - a.weight_decay * a.lr * p;
+    if (a.rectified) p = p - a.step_size * a.lr * (m / (sqrtf(v) + a.eps));
+    else if (a.step_size > 0.f) p = p - a.step_size * a.lr * m;
+    if (a.lookahead) {
+        slow = slow + a.la_alpha * (p - slow);
+        p = slow;
+    }
+}
+
+__global__ __launch_bounds__(256) void radam_kernel(const uint64_t *__restrict__ ptrs,
+                                                    const int64_t *__restrict__ sizes,
+                                                    const int32_t *__restrict__ chunks,
+                                                    const RAdamArgs a, const int use_slow)
+{
+    const int t = chunks[2 * blockIdx.x], c = chunks[2 * blockIdx.x + 1];
+    float *p = (float *)ptrs[5 * t + 0];
+    const float *g = (const float *)ptrs[5 * t + 1];
+    float *m = (float *)ptrs[5 * t + 2];
+    float *v = (float *)ptrs[5 * t + 3];
+    float *sl = (float *)ptrs[5 * t + 4];
+    const int64_t n = sizes[t];
+    const int64_t base = (int64_t)c * CHUNK;
+#pragma unroll
+    for (int it = 0; it < CHUNK / 1024; ++it) {
+        const int64_t i = base + it * 1024 + threadIdx.x * 4;
+        if (i + 3 < n) {
+            f32x4 P = *(f32x4u *)(p + i), G = *(const f32x4u *)(g + i);
+            f32x4 M = *(f32x4u *)(m + i), V = *(f32x4u *)(v + i);
+            f32x4 S = (use_slow && a.lookahead) ? *(f32x4u *)(sl + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = P[j], mj = M[j], vj = V[j], sj = S[j];
+                radam_elem(pj, G[j], mj, vj, sj, a);
+                P[j] = pj; M[j] = mj; V[j] = vj; S[j] = sj;
+            }
+            *(f32x4u *)(p + i) = P;
+            *(f32x4u *)(m + i) = M;
+            *(f32x4u *)(v + i) = V;
+            if (use_slow && a.lookahead) *(f32x4u *)(sl + i) = S;
+        } else {
+            for (int64_t j = i; j < n && j < i + 4; ++j) {
+                float s = (use_slow && a.lookahead) ? sl[j] : 0.f;
+                radam_elem(p[j], g[j], m[j], v[j], s, a);
+                if (use_slow && a.lookahead) sl[j] = s;
+            }
+        }
+    }
+}
+
+// Gradient centralisation: g[r][:] -= mean(g[r][:]), one workgroup per row.
+__global__ __launch_bounds__(256) void grad_centralize_kernel(float *g, int row_len)
+{
+    __shared__ double red[4];
+    float *row = g + (size_t)blockIdx.x * row_len;
+    double s = 0;
+    for (int i = threadIdx.x; i < row_len; i += 256) s += (double)row[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)row_len);
+    for (int i = threadIdx.x; i < row_len; i += 256) row[i] -= mean;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvsof_radam_step(const uint64_t *ptrs, const int64_t *sizes, const int32_t *chunks,
+                     int num_chunks, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float nsma_threshold, int degenerate_to_sgd,
+                     int lookahead_now, float lookahead_alpha, void *stream)
+{
+    if (!ptrs || !sizes || !chunks || num_chunks < 0 || step < 1) return DVSOF_EINVAL;
+    if (num_chunks == 0) return DVSOF_OK;
+    RAdamArgs a;
+    a.lr = lr;
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    // rectification term in double, like the Python references
+    const double b2t = pow((double)beta2, (double)step);
+    const double nmax = 2.0 / (1.0 - (double)beta2) - 1.0;
+    const double nsma = nmax - 2.0 * step * b2t / (1.0 - b2t);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    a.rectified = (degenerate_to_sgd & 2) ? nsma >= (double)nsma_threshold   // RAdam: ">="
+                                          : nsma > (double)nsma_threshold;   // Ranger: ">"
+    if (a.rectified)
+        a.step_size = (float)(sqrt((1.0 - b2t) * (nsma - 4.0) / (nmax - 4.0) * (nsma - 2.0) / nsma *
+                                   nmax / (nmax - 2.0)) / bc1);
+    else
+        a.step_size = (degenerate_to_sgd & 1) ? (float)(1.0 / bc1) : -1.f;
+    a.lookahead = lookahead_now;
+    a.la_alpha = lookahead_alpha;
+    hipLaunchKernelGGL(radam_kernel, dim3(num_chunks), dim3(256), 0, as_stream(stream), ptrs, sizes,
+                       chunks, a, lookahead_alpha > 0.f ? 1 : 0);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_grad_centralize(float *grad, int rows, int row_len, void *stream)
+{
+    if (!grad || rows < 1 || row_len < 1) return DVSOF_EINVAL;
+    hipLaunchKernelGGL(grad_centralize_kernel, dim3(rows), dim3(256), 0, as_stream(stream), grad,
+                       row_len);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+}  // extern "C"

@@ -16,23 +16,29 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _lib.register('dvsof_adamw_chunk_elems', _i, [])
 _lib.register('dvsof_adamw_step', _i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f,
                                        _i, _i, _vp])
+_lib.register('dvsof_radam_step', _i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f,
+                                       _i, _f, _i, _i, _f, _vp])
+_lib.register('dvsof_grad_centralize', _i, [_vp, _i, _i, _vp])
 
 
-class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-2, amsgrad=False):
-        defaults = dict(lr=lr, betas=betas, eps=eps,
-                        weight_decay=weight_decay, amsgrad=amsgrad)
+class _FusedBase(torch.optim.Optimizer):
+    """Shared machinery: per-group device tables of {param, grad, state...}
+    pointers, element counts and (tensor, chunk) work items."""
+    STATE = ()          # names of the 3 state tensors after param and grad
+
+    def __init__(self, params, defaults):
         super().__init__(params, defaults)
         self._tables = {}
+
+    def _init_state(self, p, st):
+        for name in self.STATE:
+            st[name] = torch.zeros_like(p)
 
     def _state(self, p):
         st = self.state[p]
         if len(st) == 0:
             st['step'] = 0
-            st['exp_avg'] = torch.zeros_like(p)
-            st['exp_avg_sq'] = torch.zeros_like(p)
-            st['max_exp_avg_sq'] = torch.zeros_like(p)
+            self._init_state(p, st)
         return st
 
     def _table(self, gi, plist):
@@ -45,8 +51,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ptrs, sizes, chunks = [], [], []
         for t, p in enumerate(plist):
             st = self._state(p)
-            for q in (p, p.grad, st['exp_avg'], st['exp_avg_sq'],
-                      st['max_exp_avg_sq']):
+            for q in (p, p.grad) + tuple(st[n] for n in self.STATE):
                 assert q.dtype == torch.float32 and q.is_cuda
                 assert q.stride() == p.stride(), \
                     'parameter, gradient and state must share one layout'
@@ -61,6 +66,9 @@ class FusedAdamW(torch.optim.Optimizer):
         t_chunks = torch.tensor(chunks, dtype=torch.int32, device=dev)
         self._tables[gi] = (key, t_ptrs, t_sizes, t_chunks, len(chunks))
         return self._tables[gi][1:]
+
+    def _launch(self, group, tables, step, plist):
+        raise NotImplementedError
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -81,15 +89,97 @@ class FusedAdamW(torch.optim.Optimizer):
                 st['step'] = int(st['step']) + 1
                 steps.add(st['step'])
             assert len(steps) == 1, 'tensors of one group step together'
-            t_ptrs, t_sizes, t_chunks, n = self._table(gi, plist)
-            b1, b2 = group['betas']
-            _lib.check(_lib.lib().dvsof_adamw_step(
-                t_ptrs.data_ptr(), t_sizes.data_ptr(), t_chunks.data_ptr(), n,
-                float(group['lr']), float(b1), float(b2), float(group['eps']),
-                float(group['weight_decay']), steps.pop(),
-                1 if group['amsgrad'] else 0, _lib.stream()),
-                'dvsof_adamw_step')
+            self._launch(group, self._table(gi, plist), steps.pop(), plist)
         return loss
+
+
+class FusedAdamW(_FusedBase):
+    STATE = ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq')
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-2, amsgrad=False):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps,
+                                      weight_decay=weight_decay,
+                                      amsgrad=amsgrad))
+
+    def _launch(self, group, tables, step, plist):
+        t_ptrs, t_sizes, t_chunks, n = tables
+        b1, b2 = group['betas']
+        _lib.check(_lib.lib().dvsof_adamw_step(
+            t_ptrs.data_ptr(), t_sizes.data_ptr(), t_chunks.data_ptr(), n,
+            float(group['lr']), float(b1), float(b2), float(group['eps']),
+            float(group['weight_decay']), step,
+            1 if group['amsgrad'] else 0, _lib.stream()), 'dvsof_adamw_step')
+
+
+class FusedRAdam(_FusedBase):
+    """Rectified Adam (Liu et al., ICLR 2020) with the defaults of the
+    ``RAdam.radam.RAdam`` class the reference builds for ``--optimizer RADAM``
+    (train_flownet.py:62-64; upstream submodule absent: parity unpinned,
+    oracle/ref_optim.py restates the published algorithm)."""
+    STATE = ('exp_avg', 'exp_avg_sq', 'slow_buffer')
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0, degenerated_to_sgd=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps,
+                                      weight_decay=weight_decay,
+                                      degenerated_to_sgd=degenerated_to_sgd))
+
+    def _init_state(self, p, st):
+        st['exp_avg'] = torch.zeros_like(p)
+        st['exp_avg_sq'] = torch.zeros_like(p)
+        st['slow_buffer'] = st['exp_avg']      # unused by the kernel
+
+    def _launch(self, group, tables, step, plist):
+        t_ptrs, t_sizes, t_chunks, n = tables
+        b1, b2 = group['betas']
+        _lib.check(_lib.lib().dvsof_radam_step(
+            t_ptrs.data_ptr(), t_sizes.data_ptr(), t_chunks.data_ptr(), n,
+            float(group['lr']), float(b1), float(b2), float(group['eps']),
+            float(group['weight_decay']), step, 5.0,
+            2 | (1 if group['degenerated_to_sgd'] else 0), 0, 0.0,
+            _lib.stream()), 'dvsof_radam_step')
+
+
+class FusedRanger(_FusedBase):
+    """Ranger = RAdam + Lookahead (k, alpha) + gradient centralisation, with
+    the defaults of lessw2020's ``ranger.Ranger`` which the reference builds
+    for its DEFAULT ``--optimizer RANGER`` (train_flownet.py:65-71,
+    utils/options.py:254-257; upstream submodule absent: parity unpinned)."""
+    STATE = ('exp_avg', 'exp_avg_sq', 'slow_buffer')
+
+    def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5,
+                 betas=(.95, 0.999), eps=1e-5, weight_decay=0, use_gc=True,
+                 gc_conv_only=False):
+        super().__init__(params, dict(
+            lr=lr, alpha=alpha, k=k, N_sma_threshhold=N_sma_threshhold,
+            betas=betas, eps=eps, weight_decay=weight_decay, use_gc=use_gc,
+            gc_conv_only=gc_conv_only))
+
+    def _init_state(self, p, st):
+        st['exp_avg'] = torch.zeros_like(p)
+        st['exp_avg_sq'] = torch.zeros_like(p)
+        st['slow_buffer'] = p.detach().clone()
+
+    def _launch(self, group, tables, step, plist):
+        lib = _lib.lib()
+        if group['use_gc']:
+            gc_dim = 3 if group['gc_conv_only'] else 1
+            for p in plist:
+                if p.dim() > gc_dim:     # mean over everything but dim 0
+                    assert p.grad.stride() == p.stride()
+                    _lib.check(lib.dvsof_grad_centralize(
+                        p.grad.data_ptr(), p.shape[0], p.numel() // p.shape[0],
+                        _lib.stream()), 'dvsof_grad_centralize')
+        t_ptrs, t_sizes, t_chunks, n = tables
+        b1, b2 = group['betas']
+        _lib.check(lib.dvsof_radam_step(
+            t_ptrs.data_ptr(), t_sizes.data_ptr(), t_chunks.data_ptr(), n,
+            float(group['lr']), float(b1), float(b2), float(group['eps']),
+            float(group['weight_decay']), step,
+            float(group['N_sma_threshhold']), 1,
+            1 if step % group['k'] == 0 else 0, float(group['alpha']),
+            _lib.stream()), 'dvsof_radam_step')
 
 
 def _dense(t):

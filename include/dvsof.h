@@ -281,6 +281,28 @@ int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes,
                      float beta1, float beta2, float eps, float weight_decay,
                      int step, int amsgrad, void *stream);
 
+
+/*
+ * Fused multi-tensor RAdam / Ranger step for one parameter group.  Replaces
+ * RAdam.radam.RAdam and ranger.Ranger (train_flownet.py:62-71; un-vendored
+ * submodules upstream -- arithmetic per Liu et al. 2020 and Lookahead, Zhang
+ * et al. 2019; oracle/ref_optim.py).  Tables as for dvsof_adamw_step;
+ * ptrs[5t+4] is the Lookahead slow buffer (Ranger) or unused (RAdam).
+ *   degenerate_to_sgd  bit 0: take an un-rectified momentum step while the
+ *                      variance is not tractable (both upstream defaults);
+ *                      bit 1: RAdam's ">= threshold" rule instead of Ranger's ">"
+ *   lookahead_now      1 on every k-th step of Ranger, else 0
+ *   lookahead_alpha    slow-weight step (0 = no slow buffer: plain RAdam)
+ */
+int dvsof_radam_step(const uint64_t *ptrs, const int64_t *sizes,
+                     const int32_t *chunks, int num_chunks, float lr,
+                     float beta1, float beta2, float eps, float weight_decay,
+                     int step, float nsma_threshold, int degenerate_to_sgd,
+                     int lookahead_now, float lookahead_alpha, void *stream);
+
+/* Gradient centralisation (Ranger): grad[r][:] -= mean(grad[r][:]). */
+int dvsof_grad_centralize(float *grad, int rows, int row_len, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

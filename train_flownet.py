@@ -19,7 +19,8 @@ import torch.optim as optim
 from dvs_of_training_framework_amd import parallel, synthetic
 from dvs_of_training_framework_amd.loss import init_losses
 from dvs_of_training_framework_amd.model import init_model
-from dvs_of_training_framework_amd.optim import FusedAdamW
+from dvs_of_training_framework_amd.optim import FusedAdamW, FusedRAdam, \
+    FusedRanger
 from dvs_of_training_framework_amd.options import (
     add_train_arguments, add_preprocessed_dataset_arguments,
     validate_train_args)
@@ -57,10 +58,11 @@ def construct_optimizer(args, params):     # train_flownet.py:57-75
         return opt(params, lr=args.lr, weight_decay=args.wdw, amsgrad=True)
     if args.optimizer in ('RADAM', 'RANGER'):
         # un-vendored submodules upstream (RAdam/, Ranger-Deep-Learning-
-        # Optimizer/): SURVEY.md section 8f rank 1, not built yet
-        raise NotImplementedError(
-            f'--optimizer {args.optimizer} is not available in this build; '
-            'use --optimizer ADAM')
+        # Optimizer/): fused HIP restatements of the published algorithms
+        assert all(p.is_cuda for g in params for p in g['params']), \
+            f'--optimizer {args.optimizer} runs on the HIP path only'
+        opt = FusedRAdam if args.optimizer == 'RADAM' else FusedRanger
+        return opt(params, lr=args.lr, weight_decay=args.wdw)
     assert hasattr(torch.optim, args.optimizer), 'Unknown optimizer type'
     return getattr(torch.optim, args.optimizer)(params, lr=args.lr,
                                                 weight_decay=args.wdw)
