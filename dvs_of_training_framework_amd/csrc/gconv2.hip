@@ -26,10 +26,10 @@
 // Same GConvParams / epilogue semantics as gconv.hip (v1), which stays as the
 // fallback for shapes this kernel does not take (see gconv2_eligible).
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int NS = 4;               // ring stages
 constexpr unsigned OOB = 0x80000000u;
 
 struct KIt {
@@ -38,7 +38,7 @@ struct KIt {
 
 }  // namespace
 
-template <int WROWS, int WCOLS, int TM, int TN>
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS>
 __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, const int nflat,
                                                          const int nvec)
 {
@@ -49,8 +49,11 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
     constexpr int PA = BM / 16;
     constexpr int PB0 = (BN + 15) / 16;
     constexpr int PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
-    constexpr int LPW = (PA + PB) / 4;            // loads per wave per stage
-    constexpr int STAGE = (PA + PB) * 1024;       // bytes
+    // a stage holds KSUB consecutive 16-channel slices of one tap (K depth
+    // 16*KSUB per barrier: halves the per-slice sync cost at 1-2 waves/SIMD)
+    constexpr int LPW = (PA + PB) / 4 * KSUB;     // loads per wave per stage
+    constexpr int SUB = (PA + PB) * 1024;         // bytes of one 16-wide slice
+    constexpr int STAGE = SUB * KSUB;
     constexpr int ROWINFO = NS * STAGE;           // byte offset of rowB/rowY/rowX
     static_assert(WROWS * WCOLS == CONV_NT / kWave, "4 waves");
 
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
             b_off[t][j] = PA * 1024 + R * 64 + (((2 * j + lh) ^ ((R >> 2) & 3)) << 4);
         }
 
-    auto compute = [&](const unsigned char *stage) {
+    auto compute1 = [&](const unsigned char *stage) {
         // all fragment reads of the slice are issued before the first MFMA so
         // that only the first pair's LDS latency is exposed
         f32x4 a[2][TM], b[2][TN];
@@ -143,6 +146,10 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             a[j][tm][i], b[j][tn][i], acc[tm][tn], 0, 0, 0);
+    };
+    auto compute = [&](const unsigned char *stage) {
+#pragma unroll
+        for (int sub = 0; sub < KSUB; ++sub) compute1(stage + sub * SUB);
     };
 
     // ------------------------------------------------------------------
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
                            (kk & 3) * 4) = v;
             }
             __syncthreads();
-            compute(smem);
+            compute1(smem);
             ++done;
             f0 += BK;
             if (f0 >= taps * S.C) {  // next flat member
@@ -208,12 +215,13 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
         // load slots of this wave: piece p = wave + 4*i, i < LPW
         //   p < PA : A rows 16p .. 16p+15 ; else B rows 16(p-PA) ..
         // lane -> row 16p + (lane>>2), slot lane&3, fetched k-quad slot ^ ((row>>2)&3)
-        int slot_row[LPW];
-        unsigned slot_kq4[LPW];       // byte offset of the fetched k-quad
-        unsigned voff[LPW];
-        int sb_[LPW], sy_[LPW], sx_[LPW];   // row info of A slots
+        constexpr int NSLOT = LPW / KSUB;   // load slots per wave per 16-wide slice
+        int slot_row[NSLOT];
+        unsigned slot_kq4[NSLOT];     // byte offset of the fetched k-quad
+        unsigned voff[NSLOT];
+        int sb_[NSLOT], sy_[NSLOT], sx_[NSLOT];   // row info of A slots
 #pragma unroll
-        for (int i = 0; i < LPW; ++i) {
+        for (int i = 0; i < NSLOT; ++i) {
             const int p = wave + 4 * i;
             const int r = (p < PA ? 16 * p : 16 * (p - PA)) + (lane >> 2);
             slot_row[i] = r;
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
             if (new_tap) {  // per-lane offsets of the A slots for this (member, tap)
                 new_tap = false;
 #pragma unroll
-                for (int i = 0; i < LPW; ++i) {
+                for (int i = 0; i < NSLOT; ++i) {
                     if (wave + 4 * i < PA) {
                         const int Y = sy_[i] + it_ky, X = sx_[i] + it_kx;
                         bool ok = ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
@@ -262,22 +270,25 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
                     }
                 }
             }
-            const int a_soff = __builtin_amdgcn_readfirstlane(it_c0 * 4);
-            const int b_soff = __builtin_amdgcn_readfirstlane(
-                ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff + it_c0) * 4);
-            unsigned char *st = smem + stage_idx * STAGE;
 #pragma unroll
-            for (int i = 0; i < LPW; ++i) {
-                const int p = wave + 4 * i;     // SGPR
-                __attribute__((address_space(3))) void *dst =
-                    (__attribute__((address_space(3))) void *)(st + p * 1024);
-                if (p < PA)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, dst, 16, voff[i], a_soff, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, voff[i], b_soff, 0, 0);
+            for (int sub = 0; sub < KSUB; ++sub) {
+                const int a_soff = __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
+                const int b_soff = __builtin_amdgcn_readfirstlane(
+                    ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff + it_c0 + sub * BK) * 4);
+                unsigned char *st = smem + stage_idx * STAGE + sub * SUB;
+#pragma unroll
+                for (int i = 0; i < LPW / KSUB; ++i) {
+                    const int p = wave + 4 * i;     // SGPR
+                    __attribute__((address_space(3))) void *dst =
+                        (__attribute__((address_space(3))) void *)(st + p * 1024);
+                    if (p < PA)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, dst, 16, voff[i], a_soff, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, voff[i], b_soff, 0, 0);
+                }
             }
             // advance: chunk inner, then tap, then the next vector member
-            it_c0 += BK;
+            it_c0 += BK * KSUB;
             if (it_c0 >= it_C) {
                 it_c0 = 0;
                 new_tap = true;
@@ -389,21 +400,21 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN>
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS>
 int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
     constexpr int PA = BM / 16, PB0 = (BN + 15) / 16, PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
-    constexpr size_t LDS = (size_t)NS * (PA + PB) * 1024 + 3 * BM * sizeof(int);
+    constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN>,
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN, P.nph);
-    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), LDS, st, P, nflat,
-                       nvec);
+    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS>), grid, dim3(CONV_NT), LDS, st,
+                       P, nflat, nvec);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
@@ -428,17 +439,26 @@ bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_
 int gconv2_launch(const GConvParams &P, int tile, hipStream_t st)
 {
     const int taps = P.ks * P.ks;
+    // K depth per barrier: 32 when every vector member allows it (small tiles
+    // run 1-2 waves per SIMD, where the per-slice sync cost is exposed)
+    static const bool k16 = getenv("DVSOF_GCONV_K16") != nullptr;
+    bool k32 = !k16 && (tile == 2 || tile == 3);
+    for (int s = 0; s < P.nsrc; ++s)
+        if (!P.src[s].flat && (P.src[s].C % (2 * BK))) k32 = false;
+    const int ksub = k32 ? 2 : 1;
     int nflat = 0, nvec = 0;
     for (int s = 0; s < P.nsrc; ++s) {
         if (P.src[s].flat) nflat += (taps * P.src[s].C + BK - 1) / BK;
-        else nvec += taps * (P.src[s].C / BK);
+        else nvec += taps * (P.src[s].C / (BK * ksub));
     }
     switch (tile) {
-    case 1: return launch2<2, 2, 2, 2>(P, nflat, nvec, st);  // 128 x 128
-    case 2: return launch2<2, 2, 2, 1>(P, nflat, nvec, st);  // 128 x 64
-    case 3: return launch2<2, 2, 1, 1>(P, nflat, nvec, st);  // 64 x 64
-    case 4: return launch2<4, 1, 2, 1>(P, nflat, nvec, st);  // 256 x 32
-    case 5: return launch2<4, 1, 1, 1>(P, nflat, nvec, st);  // 128 x 32
+    case 1: return launch2<2, 2, 2, 2, 1, 4>(P, nflat, nvec, st);  // 128 x 128
+    case 2: return k32 ? launch2<2, 2, 2, 1, 2, 3>(P, nflat, nvec, st)
+                       : launch2<2, 2, 2, 1, 1, 4>(P, nflat, nvec, st);  // 128 x 64
+    case 3: return k32 ? launch2<2, 2, 1, 1, 2, 4>(P, nflat, nvec, st)
+                       : launch2<2, 2, 1, 1, 1, 4>(P, nflat, nvec, st);  // 64 x 64
+    case 4: return launch2<4, 1, 2, 1, 1, 4>(P, nflat, nvec, st);  // 256 x 32
+    case 5: return launch2<4, 1, 1, 1, 1, 4>(P, nflat, nvec, st);  // 128 x 32
     default: return DVSOF_EINVAL;
     }
 }
