@@ -445,6 +445,11 @@ int gconv2_launch(const GConvParams &P, int tile, hipStream_t st)
     bool k32 = !k16 && (tile == 2 || tile == 3);
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].C % (2 * BK))) k32 = false;
+    {   // larger stages cost occupancy: only when the grid is <= 2 workgroups per CU anyway
+        const long long bm = 128 >> (tile == 3), bn = 64;
+        const long long blocks = ((P.M + bm - 1) / bm) * ((P.N + bn - 1) / bn) * P.nph;
+        if (blocks > 2 * 256) k32 = false;
+    }
     const int ksub = k32 ? 2 : 1;
     int nflat = 0, nvec = 0;
     for (int s = 0; s < P.nsrc; ++s) {
