@@ -647,7 +647,14 @@ int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)
     if (kind == 0) return gconv_pick_tile((long long)d->B * Ho * Wo, d->Cout);
     if (kind == 1) {
         const int up = (d->upsample && !is_subpixel(d)) ? 2 : 1;
-        return gconv_pick_tile((long long)d->B * d->H * up * d->W * up, Ctot);  // phases included
+        int n = Ctot, trail = 0;   // narrow planar members are peeled off (gconv.hip)
+        for (int i = d->nsrc - 1; i > 0; --i) {
+            const GSrc g = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+            if (!g.flat || trail + g.C > 4) break;
+            trail += g.C;
+        }
+        if (up == 1 && !(is_stride2_phased(d)) && n - trail >= 32) n -= trail;
+        return gconv_pick_tile((long long)d->B * d->H * up * d->W * up, n);  // phases included
     }
     if (kind == 2) {
         WGradParams P;

@@ -344,6 +344,74 @@ int gconv_pick_tile(long long m, long long n)
     return best;
 }
 
+// ---- trailing "flat" output channel ranges (the 2-channel flow gradient of a
+// decoder data-gradient) on the VALU: out[m][n] = sum_k A[m][k] * W[n][k] for
+// the few rows n >= n_begin of W.  Keeps them out of the MFMA problem, whose N
+// is then 128/256/512 instead of 130/258/514 (one fewer column tile, and
+// 128-wide tiles with no padding).  One wave per output pixel, lanes split K.
+namespace {
+constexpr int FLATN_MAX = 4;
+
+__global__ __launch_bounds__(256) void gconv_flat_rows_kernel(const GConvParams P, const int n_begin,
+                                                              const int nrows)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    const GSrc &S = P.src[0];
+    const int taps = P.ks * P.ks, K = taps * S.C;
+    const size_t wrow = (size_t)taps * P.Cin_tot;
+    // destination of row n (rows are consecutive inside the trailing dsts)
+    for (long long m = wave_id; m < P.M; m += nwaves) {
+        const int ox = (int)(m % P.Wo);
+        const long long t = m / P.Wo;
+        const int oy = (int)(t % P.Ho), b = (int)(t / P.Ho);
+        float acc[FLATN_MAX] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 4 * lane; k < K; k += 256) {
+            const int tap = k / S.C, c = k - tap * S.C;
+            const int ky = tap / P.ks, kx = tap - ky * P.ks;
+            const int Y = oy * P.stride - P.pad + ky, X = ox * P.stride - P.pad + kx;
+            if ((unsigned)Y < (unsigned)P.Hv && (unsigned)X < (unsigned)P.Wv) {
+                const f32x4 a = *(const f32x4u *)(S.p + (size_t)b * S.sb + (size_t)Y * S.sy +
+                                                  (size_t)X * S.sx + c);
+#pragma unroll
+                for (int r = 0; r < FLATN_MAX; ++r)
+                    if (r < nrows) {
+                        const f32x4 w = *(const f32x4u *)(P.W + (size_t)(n_begin + r) * wrow +
+                                                          (size_t)tap * P.Cin_tot + c);
+                        acc[r] += a[0] * w[0] + a[1] * w[1] + a[2] * w[2] + a[3] * w[3];
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FLATN_MAX; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+            int d = 0, off = 0;
+            for (int dd = 0; dd + 1 < P.ndst; ++dd)
+                if (n_begin >= off + P.dst[dd].C && d == dd) {
+                    off += P.dst[dd].C;
+                    d = dd + 1;
+                }
+            for (int r = 0; r < nrows; ++r) {
+                int n = n_begin + r;
+                while (n >= off + P.dst[d].C) {
+                    off += P.dst[d].C;
+                    ++d;
+                }
+                const GDst &D = P.dst[d];
+                const size_t o = (size_t)b * D.sb + (size_t)oy * D.sy + (size_t)ox * D.sx +
+                                 (size_t)(n - off) * D.sc;
+                float v = acc[r];
+                if (D.addend) v += D.addend[o];
+                if (D.addend2) v += D.addend2[o];
+                if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
+                D.p[o] = v;
+            }
+        }
+    }
+}
+}  // namespace
+
 bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_bytes);
 int gconv2_launch(const GConvParams &P, int tile, hipStream_t st);
 bool gconv3_eligible(const GConvParams &P, int tile, long long max_src_bytes, long long w_bytes);
@@ -359,6 +427,30 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
     if (P.nph != 1 && P.nph != 4) return DVSOF_EINVAL;
     for (int s = 0; s < P.nsrc; ++s)
         if (!P.src[s].flat && (P.src[s].sc != 1 || (P.src[s].C & 3))) return DVSOF_EINVAL;
+    // data-gradient form with trailing narrow planar destinations: peel them off
+    {
+        static const bool no_split = getenv("DVSOF_GCONV_NO_SPLIT") != nullptr;
+        int ntrail = 0, d = P.ndst;
+        while (d > 1 && (P.dst[d - 1].sc != 1 || P.dst[d - 1].C < BK) && ntrail + P.dst[d - 1].C <= FLATN_MAX) {
+            ntrail += P.dst[d - 1].C;
+            --d;
+        }
+        if (!no_split && ntrail > 0 && P.nsrc == 1 && !P.src[0].flat && P.src[0].sc == 1 &&
+            (P.src[0].C & 3) == 0 && P.up == UP_NONE && !P.quad && P.nph == 1 && !P.bias &&
+            !P.zout && P.act == ACT_NONE && P.N - ntrail >= 32) {
+            GConvParams Q = P;
+            Q.N = P.N - ntrail;
+            Q.ndst = d;
+            const int rc = gconv_launch(Q, tile_hint, st);
+            if (rc) return rc;
+            long long nb = ((long long)P.M + 3) / 4;
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(gconv_flat_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, P, Q.N,
+                               ntrail);
+            DVSOF_LAUNCH_CHECK();
+            return DVSOF_OK;
+        }
+    }
     const int tile = tile_hint > 0 ? tile_hint : gconv_pick_tile((long long)P.M * P.nph, P.N);
     {   // v2 (LDS-DMA ring, VALU-free main loop) when the shape allows it
         static const bool force_v1 = getenv("DVSOF_GCONV_V1") != nullptr;
