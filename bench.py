@@ -42,6 +42,8 @@ def kernel_name(family, tile, gen):
     """Name as rocprofv3 reports it (kernel template + tile shape)."""
     if gen == 0:
         return 'wgrad_flat_kernel (VALU, flat members)'
+    # (gconv2 instantiations carry two more template arguments in rocprof
+    # output: K slices per stage and ring depth, e.g. <2,2,1,1,2,4>)
     return f"{family}{'2' if gen == 2 else ''}_kernel{TILE_SHAPES[family][tile]}"
 
 
