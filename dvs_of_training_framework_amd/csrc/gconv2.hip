@@ -38,9 +38,12 @@ struct KIt {
 
 }  // namespace
 
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS>
-__global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, const int nflat,
-                                                         const int nvec)
+// KSPLIT = 2: 8 waves; wave group g = wave/4 loads and multiplies sub-slice g of
+// every K-32 stage (two waves per SIMD even when the grid only offers one
+// workgroup per CU), the two accumulator sets are added through LDS at the end.
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT>
+__global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvParams P,
+                                                                 const int nflat, const int nvec)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins/types below
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
@@ -51,7 +54,10 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
     constexpr int PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
     // a stage holds KSUB consecutive 16-channel slices of one tap (K depth
     // 16*KSUB per barrier: halves the per-slice sync cost at 1-2 waves/SIMD)
-    constexpr int LPW = (PA + PB) / 4 * KSUB;     // loads per wave per stage
+    static_assert(KSPLIT == 1 || KSUB == 2, "wave groups split the two sub-slices");
+    constexpr int NT = CONV_NT * KSPLIT;
+    constexpr int KPW = KSUB / KSPLIT;            // sub-slices a wave loads and multiplies
+    constexpr int LPW = (PA + PB) / 4 * KPW;      // loads per wave per stage
     constexpr int SUB = (PA + PB) * 1024;         // bytes of one 16-wide slice
     constexpr int STAGE = SUB * KSUB;
     constexpr int ROWINFO = NS * STAGE;           // byte offset of rowB/rowY/rowX
@@ -63,7 +69,8 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform values must live in SGPRs: otherwise hipcc wraps every
     // LDS-DMA in a waterfall loop over "possibly divergent" descriptors
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, wgrp = wave8 >> 2;   // wgrp = sub-slice owned (KSPLIT = 2)
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int taps = P.ks * P.ks;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
     const float *Wp = P.W + (size_t)ph * P.w_phase_stride;
     const size_t wrow = (size_t)taps * P.Cin_tot;
 
-    for (int r = tid; r < BM; r += CONV_NT) {
+    for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         int b = 0, y = -(1 << 20), x = -(1 << 20);
         if (m < P.M) {
@@ -149,13 +156,13 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
     };
     auto compute = [&](const unsigned char *stage) {
 #pragma unroll
-        for (int sub = 0; sub < KSUB; ++sub) compute1(stage + sub * SUB);
+        for (int sub = 0; sub < KPW; ++sub) compute1(stage + (sub + wgrp * KPW) * SUB);
     };
 
     // ------------------------------------------------------------------
     // flat concat members first: synchronous register path into stage 0
     // ------------------------------------------------------------------
-    if (nflat > 0) {
+    if (KSPLIT == 1 && nflat > 0) {
         int s = 0, coff = 0, f0 = 0, done = 0;
         while (!P.src[s].flat) {
             coff += P.src[s].C;
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
         // load slots of this wave: piece p = wave + 4*i, i < LPW
         //   p < PA : A rows 16p .. 16p+15 ; else B rows 16(p-PA) ..
         // lane -> row 16p + (lane>>2), slot lane&3, fetched k-quad slot ^ ((row>>2)&3)
-        constexpr int NSLOT = LPW / KSUB;   // load slots per wave per 16-wide slice
+        constexpr int NSLOT = LPW / KPW;    // load slots per wave per 16-wide slice
         int slot_row[NSLOT];
         unsigned slot_kq4[NSLOT];     // byte offset of the fetched k-quad
         unsigned voff[NSLOT];
@@ -271,13 +278,14 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
                 }
             }
 #pragma unroll
-            for (int sub = 0; sub < KSUB; ++sub) {
+            for (int sub0 = 0; sub0 < KPW; ++sub0) {
+                const int sub = sub0 + wgrp * KPW;
                 const int a_soff = __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
                 const int b_soff = __builtin_amdgcn_readfirstlane(
                     ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff + it_c0 + sub * BK) * 4);
                 unsigned char *st = smem + stage_idx * STAGE + sub * SUB;
 #pragma unroll
-                for (int i = 0; i < LPW / KSUB; ++i) {
+                for (int i = 0; i < NSLOT; ++i) {
                     const int p = wave + 4 * i;     // SGPR
                     __attribute__((address_space(3))) void *dst =
                         (__attribute__((address_space(3))) void *)(st + p * 1024);
@@ -343,6 +351,27 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
         }
     }
 
+    if (KSPLIT == 2) {   // add the second wave group's accumulators (ring memory is free now)
+        __syncthreads();
+        float *xch = (float *)smem + (size_t)wave * (TM * TN * 16 * 64);
+        if (wgrp == 1) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((a * TN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (wgrp == 1) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += xch[((a * TN + b) * 16 + r) * 64 + lane];
+    }
+
     // ---- epilogue (as in gconv.hip)
     const int sshift = P.stride - 1;
 #pragma unroll
@@ -400,7 +429,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv2_kernel(const GConvParams P, co
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS>
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT = 1>
 int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
@@ -408,13 +437,13 @@ int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
     constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS>,
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN, P.nph);
-    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS>), grid, dim3(CONV_NT), LDS, st,
-                       P, nflat, nvec);
+    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT>), grid,
+                       dim3(CONV_NT * KSPLIT), LDS, st, P, nflat, nvec);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
@@ -460,8 +489,15 @@ int gconv2_launch(const GConvParams &P, int tile, hipStream_t st)
     case 1: return launch2<2, 2, 2, 2, 1, 4>(P, nflat, nvec, st);  // 128 x 128
     case 2: return k32 ? launch2<2, 2, 2, 1, 2, 3>(P, nflat, nvec, st)
                        : launch2<2, 2, 2, 1, 1, 4>(P, nflat, nvec, st);  // 128 x 64
-    case 3: return k32 ? launch2<2, 2, 1, 1, 2, 4>(P, nflat, nvec, st)
-                       : launch2<2, 2, 1, 1, 1, 4>(P, nflat, nvec, st);  // 64 x 64
+    case 3: {
+        // <= 1 workgroup per CU: 8-wave form (two waves per SIMD from one workgroup)
+        static const bool no8 = getenv("DVSOF_GCONV_NO_KSPLIT") != nullptr;
+        const long long blocks = ((P.M + 63) / 64) * ((P.N + 63) / 64) * P.nph;
+        if (k32 && !no8 && nflat == 0 && blocks <= 256)
+            return launch2<2, 2, 1, 1, 2, 4, 2>(P, nflat, nvec, st);
+        return k32 ? launch2<2, 2, 1, 1, 2, 4>(P, nflat, nvec, st)
+                   : launch2<2, 2, 1, 1, 1, 4>(P, nflat, nvec, st);  // 64 x 64
+    }
     case 4: return launch2<4, 1, 2, 1, 1, 4>(P, nflat, nvec, st);  // 256 x 32
     case 5: return launch2<4, 1, 1, 1, 1, 4>(P, nflat, nvec, st);  // 128 x 32
     default: return DVSOF_EINVAL;
