@@ -251,13 +251,13 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     h = Harness(a, rank, device)
-    if world > 1:
+    if world > 1 or os.environ.get('DVSOF_FORCE_DIST') == '1':
         parallel.broadcast_parameters(h.model)
         h.reducer = parallel.GradReducer()
         h.model.predictor.reducer = h.reducer
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
     for _ in range(a.warmup):
         h.step()
@@ -303,7 +303,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(a)
         print(json.dumps(out), flush=True)
     barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

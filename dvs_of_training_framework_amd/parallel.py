@@ -21,7 +21,8 @@ def init_distributed(device_type='cuda'):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('DVSOF_FORCE_DIST') == '1'    # 1-rank group: exercises the RCCL path
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         backend = 'nccl' if device_type == 'cuda' else 'gloo'
@@ -51,7 +52,8 @@ class GradReducer:
         return self._side
 
     def bucket_ready(self, flat):
-        if not self.enabled or self.world == 1:
+        if not self.enabled or (self.world == 1 and
+                                os.environ.get('DVSOF_FORCE_DIST') != '1'):
             return
         self.bytes_reduced += flat.numel() * flat.element_size()
         if flat.is_cuda:
