@@ -215,36 +215,61 @@ constexpr int COLSUM_MAX_BLOCKS = 512;
 
 int colsum_blocks(long long rows)
 {
-    const long long nb = (rows + 63) / 64;
+    const long long nb = (rows + 127) / 128;
     return (int)(nb < 1 ? 1 : nb > COLSUM_MAX_BLOCKS ? COLSUM_MAX_BLOCKS : nb);
 }
 
-// part[block][c] = sum over this block's rows of g[row][c]   (g dense [rows][C])
+// part[block][c] = sum over this block's rows of g[row][c]   (g dense [rows][C]).
+// C % 4 == 0: C/4 lanes per row load float4 (whole rows = contiguous bytes),
+// 256/(C/4) rows in flight per pass, 4 passes unrolled.
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g, long long rows,
                                                      int C, float *__restrict__ part)
 {
-    __shared__ float red[256];
+    __shared__ f32x4 red[256];
     const int tid = threadIdx.x;
     const long long per = (rows + gridDim.x - 1) / gridDim.x;
     const long long r0 = (long long)blockIdx.x * per;
     const long long r1 = r0 + per < rows ? r0 + per : rows;
-    for (int c0 = 0; c0 < C; c0 += 256) {
-        // 256 threads = G channel lanes x RP row lanes
-        const int G = (C - c0) < 256 ? (C - c0) : 256;
-        int RP = 256 / G;
-        if (RP < 1) RP = 1;
+    const int C4 = C >> 2;
+    for (int c0 = 0; c0 < C4; c0 += 256) {
+        const int G = (C4 - c0) < 256 ? (C4 - c0) : 256;   // float4 lanes per row
+        const int RP = 256 / G;                             // rows per pass
         const int c = tid % G, rl = tid / G;
-        float a = 0.f;
-        if (rl < RP)
-            for (long long r = r0 + rl; r < r1; r += RP) a += g[r * C + c0 + c];
-        red[tid] = a;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        if (rl < RP) {
+            const float *base = g + (size_t)(c0 + c) * 4;
+            long long r = r0 + rl;
+            for (; r + 3 * RP < r1; r += 4 * RP) {
+                a0 += *(const f32x4u *)(base + (size_t)r * C);
+                a1 += *(const f32x4u *)(base + (size_t)(r + RP) * C);
+                a2 += *(const f32x4u *)(base + (size_t)(r + 2 * RP) * C);
+                a3 += *(const f32x4u *)(base + (size_t)(r + 3 * RP) * C);
+            }
+            for (; r < r1; r += RP) a0 += *(const f32x4u *)(base + (size_t)r * C);
+        }
+        red[tid] = (a0 + a1) + (a2 + a3);
         __syncthreads();
         if (tid < G) {
-            float t = 0.f;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < RP; ++k) t += red[k * G + tid];
-            part[(size_t)blockIdx.x * C + c0 + tid] = t;
+            *(f32x4u *)(part + (size_t)blockIdx.x * C + (size_t)(c0 + tid) * 4) = t;
         }
         __syncthreads();
+    }
+}
+
+// scalar fallback for C % 4 != 0
+__global__ __launch_bounds__(256) void colsum_scalar_kernel(const float *__restrict__ g,
+                                                            long long rows, int C,
+                                                            float *__restrict__ part)
+{
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per;
+    const long long r1 = r0 + per < rows ? r0 + per : rows;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (long long r = r0; r < r1; ++r) a += g[r * C + c];
+        part[(size_t)blockIdx.x * C + c] = a;
     }
 }
 
@@ -564,7 +589,11 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
         const long long rows = (long long)P.B * (P.g_sb / P.Cout);
         float *part = ws + (direct ? 0 : (size_t)nslab * wsize);
         const int nb = colsum_blocks(rows);
-        hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, P.gout, rows, P.Cout, part);
+        if (P.Cout & 3)
+            hipLaunchKernelGGL(colsum_scalar_kernel, dim3(nb), dim3(256), 0, st, P.gout, rows, P.Cout,
+                               part);
+        else
+            hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, P.gout, rows, P.Cout, part);
         DVSOF_LAUNCH_CHECK();
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((P.Cout + 1023) / 1024)), dim3(256),
                            0, st, (const float *)part, dbias, (size_t)P.Cout, nb);
