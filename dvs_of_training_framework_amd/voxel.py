@@ -47,11 +47,15 @@ def voxelize(events, t0, t1, B, C, H, W, debug=False):
     if debug:
         bin0 = torch.empty(max(n, 1), dtype=torch.int32, device=t0.device)
         lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=t0.device)
-    _lib.check(_lib.lib().dvsof_voxelize_fwd(
+    lib = _lib.lib()
+    nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=t0.device) \
+        if nbytes else None
+    _lib.check(lib.dvsof_voxelize_tiled(
         x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(), s.data_ptr(),
         n, t0.contiguous().data_ptr(), t1.contiguous().data_ptr(), B, C, H, W,
-        out.data_ptr(), _lib.ptr(bin0), _lib.ptr(lin0), _lib.stream()),
-        'dvsof_voxelize_fwd')
+        out.data_ptr(), _lib.ptr(bin0), _lib.ptr(lin0), _lib.ptr(ws), nbytes,
+        _lib.stream()), 'dvsof_voxelize_tiled')
     if debug:
         return out, bin0[:n], lin0[:n]
     return out

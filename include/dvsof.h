@@ -71,6 +71,23 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t,
                        int B, int C, int H, int W, float *out, int32_t *bin0,
                        int64_t *lin0, void *stream);
 
+/*
+ * Same result through LDS-staged voxel tiles: events are bucketed per 32x32
+ * tile in one coalesced pass, each tile is accumulated in LDS and stored with
+ * plain coalesced writes (no zero-fill, no global float atomics unless a
+ * bucket overflows).  Falls back to dvsof_voxelize_fwd for tiny inputs or when
+ * the workspace is missing/too small.  Integer parts are identical; float
+ * sums differ only in accumulation order.
+ */
+size_t dvsof_voxelize_workspace_bytes(int64_t n_events, int B, int C, int H,
+                                      int W);
+int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t,
+                         const int64_t *polarity, const int64_t *sample_index,
+                         int64_t n_events, const float *t0, const float *t1,
+                         int B, int C, int H, int W, float *out, int32_t *bin0,
+                         int64_t *lin0, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ *
  * Multi-scale warp / Charbonnier / smoothness / out-of-border loss
  * ------------------------------------------------------------------ */

@@ -75,3 +75,28 @@ def test_count_image_fixture(fixtures):
     assert np.array_equal(got, orc.count_image(ev[:, 0].astype(np.int64),
                                                ev[:, 1].astype(np.int64),
                                                260, 346))
+
+
+def test_voxelize_tiled_overflow_and_ragged():
+    """LDS-tiled path: all events of one sample crowd into a few pixels (bucket
+    overflow -> overflow list), another sample is empty, frame not a multiple
+    of the tile; integer parts bit-exact, sums within the float-atomics budget."""
+    from dvs_of_training_framework_amd.voxel import voxelize
+    B, C, H, W, n = 3, 5, 70, 90, 30000
+    rng = np.random.default_rng(21)
+    ev = synthetic.make_events(rng, B, H, W, n)
+    crowd = ev['sample_index'] == 0
+    ev['x'][crowd] = rng.integers(3, 6, crowd.sum())
+    ev['y'][crowd] = rng.integers(40, 42, crowd.sum())
+    keep = ev['sample_index'] != 1                 # sample 1 gets no events
+    ev = {k: v[keep] for k, v in ev.items()}
+    t0 = np.zeros(B, np.float32)
+    t1 = np.full(B, synthetic.WINDOW, np.float32)
+    want, bin0, lin0 = orc.voxelize(ev, t0, t1, B, C, H, W)
+    got, gbin, glin = voxelize(dev_events(ev), torch.from_numpy(t0).cuda(),
+                               torch.from_numpy(t1).cuda(), B, C, H, W, debug=True)
+    assert np.array_equal(gbin.cpu().numpy(), bin0)
+    assert np.array_equal(glin.cpu().numpy(), lin0)
+    # thousands of +-1 weights pile up on 6 pixels: tolerance scales with the count
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=5e-3)
+    assert float(got[1].abs().max()) == 0.0
