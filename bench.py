@@ -126,6 +126,27 @@ def executed_flops(desc, kind):
     return f
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC
+    passes (profiles/round1/e_traffic_pmc.csv: FETCH_SIZE x2 for the gfx950
+    under-count + WRITE_SIZE, separate --pmc runs of tools/conv_bench.py on the
+    same workload).  PMC cannot be collected from inside this process, so this
+    is a recorded measurement, not a live one; None if the file is absent."""
+    import csv
+    path = ROOT / 'profiles' / 'round1' / 'e_traffic_pmc.csv'
+    if not path.exists():
+        return None
+    prefix = kernel.split('>')[0]          # e.g. gconv2_kernel<2,2,1,1
+    num = den = 0.0
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row['k'].startswith(prefix + ',') or row['k'] == prefix + '>':
+                n = float(row['n'])
+                num += n * (float(row['fetch_MB']) + float(row['write_MB'])) * 1e6
+                den += n
+    return round(num / den) if den else None
+
+
 def measure_roofline(h, steps=3):
     """Per-launch HIP-event timing of every conv-stack launch on torch's
     current stream (= the launch stream); groups by kernel template."""
@@ -177,7 +198,8 @@ def measure_roofline(h, steps=3):
             'achieved': round(fl / sec / 1e12, 2),
             'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(fl / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
-            'traffic': None,
+            'traffic': pmc_traffic(dom),
+            'traffic_source': 'profiles/round1/e_traffic_pmc.csv (recorded PMC pass; bytes/launch)',
             'avg_launch_us': round(sec / n * 1e6, 2),
             'gflop_per_launch': round(fl / n / 1e9, 3),
             # FLOPs actually issued to the matrix cores (sub-pixel / phased
