@@ -215,11 +215,15 @@ def test_fused_radam_ranger_match_restatement(kind):
     assert set(fo.state_dict()['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq', 'slow_buffer'}
 
 
-def test_predictor_full_size_vs_aten_gpu_and_determinism():
-    """BASELINE config-2 size (B=8, 256x256x5): flows and every parameter
-    gradient against the ATen GPU path of the same restatement (plain fp32
-    ops, no TF32 on this hardware), within 1e-3 of each tensor's peak; two runs
-    of the HIP path are bitwise identical (slab reductions, no float atomics)."""
+def test_predictor_full_size_vs_float64_and_determinism():
+    """BASELINE config-2 size (B=8, 256x256x5).  Reference = the same
+    restatement evaluated in float64 on the host.  Flows within 1e-3 of the
+    peak.  Parameter gradients: any fp32 implementation differs from float64 by
+    ReLU-mask flips of activations within ~1e-6 of zero, so the pin is on the
+    field norm (3e-3); measured on MI355X the HIP path is at 0.3e-3..1.5e-3,
+    ATen/MIOpen's own GPU fp32 path at 0.3e-3..4.7e-3 (tools/dbg_fullsize.py).
+    Two runs of the HIP path are bitwise identical (fixed-order slab
+    reductions, no float atomics in the conv stack)."""
     from dvs_of_training_framework_amd.predictor import Predictor
     torch.manual_seed(2)
     B, Cin, H, W = 8, 5, 256, 256
@@ -240,17 +244,14 @@ def test_predictor_full_size_vs_aten_gpu_and_determinism():
         assert torch.equal(a, b)
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n
-    state = {k: v.detach().clone().contiguous().requires_grad_(True)
+    state = {k: v.detach().cpu().double().contiguous().requires_grad_(True)
              for k, v in net.state_dict().items()}
-    ref = ref_predictor(state, x)
-    torch.autograd.backward(ref, gfl)
+    ref = ref_predictor(state, x.cpu().double())
+    torch.autograd.backward(ref, [g.cpu().double() for g in gfl])
     for a, r in zip(f1, ref):
+        r = r.detach().float().cuda()
         assert (a - r).abs().max() <= 1e-3 * r.abs().max()
-    # Gradients: at this size two fp32 implementations differ by ReLU-mask
-    # flips of activations within ~1e-6 of zero (and MIOpen may pick Winograd
-    # kernels), so the gradient pin against ATen-GPU is on the field norm;
-    # the tight 1e-3 max-abs pin is the small-size test against ATen-CPU.
     for n, g in g1.items():
-        r = state[n].grad
-        assert (g - r).norm() <= 5e-3 * r.norm() + 1e-9, n
+        r = state[n].grad.float().cuda()
+        assert (g - r).norm() <= 3e-3 * r.norm() + 1e-9, n
         assert (g - r).abs().max() <= 2e-2 * r.abs().max() + 1e-9, n
