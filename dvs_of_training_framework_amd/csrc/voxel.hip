@@ -114,7 +114,15 @@ constexpr int EPT = 4;            // events per thread in pass 1
 constexpr int V2_MAX_TILES = 8192;
 
 struct VoxV2 {
+    // wire format (int64 columns) ...
     const int64_t *x, *y, *pol, *sample;
+    // ... or the reference's encoded columns (utils/dataset.py:286-289):
+    // int16 x, int16 y, bool polarity; the sample of event i is found in
+    // ev_off[B+1] (first event of every sample)
+    const int16_t *x16, *y16;
+    const uint8_t *p8;
+    const int64_t *ev_off;
+    int enc;
     const float *t, *t0, *t1;
     int64_t n;
     int B, C, H, W, TX, TY, ntile, cap;
@@ -144,7 +152,24 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
         const int64_t i = e0 + (int64_t)k * NT;   // coalesced across the workgroup
         tile[k] = -1;
         if (i < P.n) {
-            const int64_t b = P.sample[i], xi = P.x[i], yi = P.y[i];
+            int64_t b, xi, yi;
+            bool neg;
+            if (P.enc) {
+                xi = P.x16[i];
+                yi = P.y16[i];
+                neg = P.p8[i] == 0;
+                int lo = 0, hi = P.B;          // last sample with ev_off <= i
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (P.ev_off[mid] <= i) lo = mid; else hi = mid;
+                }
+                b = lo;
+            } else {
+                b = P.sample[i];
+                xi = P.x[i];
+                yi = P.y[i];
+                neg = P.pol[i] < 0;
+            }
             int c0 = -1;
             int64_t l = -1;
             if (b >= 0 && b < P.B && xi >= 0 && xi < P.W && yi >= 0 && yi < P.H) {
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
                     const int ty = (int)yi / VT, tx = (int)xi / VT;
                     tile[k] = ((int)b * P.TY + ty) * P.TX + tx;
                     key[k] = (unsigned)(((int)yi - ty * VT) * VT + ((int)xi - tx * VT)) |
-                             ((unsigned)c0 << 10) | (P.pol[i] < 0 ? 0x80000000u : 0u);
+                             ((unsigned)c0 << 10) | (neg ? 0x80000000u : 0u);
                     rank[k] = atomicAdd(&hist[tile[k]], 1);
                 }
             }
@@ -253,12 +278,36 @@ size_t v2_bytes(const VoxV2 &P, int64_t n)
 
 }  // namespace
 
+namespace {
+// encoded columns -> wire columns (fallback path of dvsof_voxelize_encoded)
+__global__ __launch_bounds__(NT) void expand_encoded_kernel(
+    const int16_t *__restrict__ x16, const int16_t *__restrict__ y16,
+    const uint8_t *__restrict__ p8, const int64_t *__restrict__ ev_off, int B, int64_t n,
+    int64_t *__restrict__ x, int64_t *__restrict__ y, int64_t *__restrict__ pol,
+    int64_t *__restrict__ sample)
+{
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        x[i] = x16[i];
+        y[i] = y16[i];
+        pol[i] = p8[i] ? 1 : -1;
+        int lo = 0, hi = B;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ev_off[mid] <= i) lo = mid; else hi = mid;
+        }
+        sample[i] = lo;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 size_t dvsof_voxelize_workspace_bytes(int64_t n_events, int B, int C, int H, int W)
 {
     VoxV2 P;
-    if (n_events < 4096 || !v2_plan(n_events, B, C, H, W, P)) return 0;   // v1: no workspace
+    // small inputs take the v1 kernel; the encoded entry then expands the
+    // columns into the workspace (4 int64 columns)
+    if (n_events < 4096 || !v2_plan(n_events, B, C, H, W, P)) return (size_t)n_events * 32 + 64;
     return v2_bytes(P, n_events);
 }
 
@@ -279,7 +328,57 @@ int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t, con
     P.records = (uint2 *)w;
     w += (size_t)P.ntile * P.cap * 8;
     P.ovf = (int4 *)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+    P.enc = 0;
+    P.x16 = P.y16 = nullptr;
+    P.p8 = nullptr;
+    P.ev_off = nullptr;
     P.x = x; P.y = y; P.pol = pol; P.sample = sample; P.t = t; P.t0 = t0; P.t1 = t1;
+    P.n = n; P.B = B; P.C = C; P.H = H; P.W = W;
+    P.out = out; P.bin0 = bin0; P.lin0 = lin0;
+    DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, ((size_t)P.ntile + 1) * 4, st));
+    const int nb = (int)((n + (int64_t)NT * EPT - 1) / ((int64_t)NT * EPT));
+    hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb), dim3(NT), (size_t)P.ntile * 8, st, P);
+    DVSOF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), (size_t)C * VT * VT * 4, st, P);
+    DVSOF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_overflow_kernel, dim3(64), dim3(NT), 0, st, P);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
+                           const uint8_t *polarity, const int64_t *sample_event_offsets, int64_t n,
+                           const float *t0, const float *t1, int B, int C, int H, int W, float *out,
+                           int32_t *bin0, int64_t *lin0, void *workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    if (!out || B < 1 || C < 1 || H < 1 || W < 1 || n < 0 || !t0 || !t1) return DVSOF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {
+        DVSOF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * H * W, st));
+        return DVSOF_OK;
+    }
+    if (!x || !y || !t || !polarity || !sample_event_offsets || !workspace) return DVSOF_EINVAL;
+    VoxV2 P;
+    if (n < 4096 || !v2_plan(n, B, C, H, W, P) || workspace_bytes < v2_bytes(P, n)) {
+        if (workspace_bytes < (size_t)n * 32) return DVSOF_ENOSPACE;
+        int64_t *wx = (int64_t *)workspace, *wy = wx + n, *wp = wy + n, *wsmp = wp + n;
+        hipLaunchKernelGGL(expand_encoded_kernel, dim3(grid_for(n)), dim3(NT), 0, st, x, y, polarity,
+                           sample_event_offsets, B, n, wx, wy, wp, wsmp);
+        DVSOF_LAUNCH_CHECK();
+        return dvsof_voxelize_fwd(wx, wy, t, wp, wsmp, n, t0, t1, B, C, H, W, out, bin0, lin0, stream);
+    }
+    unsigned char *w = (unsigned char *)workspace;
+    P.cursor = (int32_t *)w;
+    P.ovf_count = P.cursor + P.ntile;
+    w += ((size_t)P.ntile + 64) * 4;
+    P.records = (uint2 *)w;
+    w += (size_t)P.ntile * P.cap * 8;
+    P.ovf = (int4 *)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+    P.enc = 1;
+    P.x16 = x; P.y16 = y; P.p8 = polarity; P.ev_off = sample_event_offsets;
+    P.x = P.y = P.pol = P.sample = nullptr;
+    P.t = t; P.t0 = t0; P.t1 = t1;
     P.n = n; P.B = B; P.C = C; P.H = H; P.W = W;
     P.out = out; P.bin0 = bin0; P.lin0 = lin0;
     DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, ((size_t)P.ntile + 1) * 4, st));

@@ -49,8 +49,7 @@ def voxelize(events, t0, t1, B, C, H, W, debug=False):
         lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=t0.device)
     lib = _lib.lib()
     nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=t0.device) \
-        if nbytes else None
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=t0.device)
     _lib.check(lib.dvsof_voxelize_tiled(
         x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(), s.data_ptr(),
         n, t0.contiguous().data_ptr(), t1.contiguous().data_ptr(), B, C, H, W,

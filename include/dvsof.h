@@ -88,6 +88,21 @@ int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t,
                          int64_t *lin0, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/*
+ * The same grid from the reference's ENCODED event columns (encode_batch,
+ * utils/dataset.py:240-305: int16 x, int16 y, float32 timestamp, bool
+ * polarity = 9 bytes/event instead of 44).  sample_event_offsets[B+1] = index
+ * of the first event of every sample (from events_per_element /
+ * elements_per_sample).  Workspace: dvsof_voxelize_workspace_bytes.
+ */
+int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
+                           const uint8_t *polarity,
+                           const int64_t *sample_event_offsets,
+                           int64_t n_events, const float *t0, const float *t1,
+                           int B, int C, int H, int W, float *out,
+                           int32_t *bin0, int64_t *lin0, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ *
  * Multi-scale warp / Charbonnier / smoothness / out-of-border loss
  * ------------------------------------------------------------------ */
