@@ -70,6 +70,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
     __shared__ int rowB[BM], rowY[BM], rowX[BM];
+    __shared__ long long rowO[3 * BM];   // output offsets (conv_epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WCOLS, wc = wave % WCOLS;
@@ -81,9 +82,8 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
 
     for (int r = tid; r < BM; r += CONV_NT) {
         const int m = m0 + r;
-        int b = 0, y = -(1 << 20), x = -(1 << 20);
+        int b = 0, y = -(1 << 20), x = -(1 << 20), oy = 0, ox = 0;
         if (m < P.M) {
-            int oy, ox;
             if (!P.quad) {
                 ox = m % P.Wo;
                 const int t = m / P.Wo;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
         rowB[r] = b;
         rowY[r] = y;
         rowX[r] = x;
+        conv_row_offsets(P, rowO, BM, r, m < P.M, b, oy, ox, phy, phx);
     }
     __syncthreads();
 
@@ -242,58 +243,8 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
         __syncthreads();
     }
 
-    const int sshift = P.stride - 1;  // stride is 1 or 2
-    // ---- epilogue: acc[reg] <-> row (reg&3) + 8*(reg>>2) + 4*(lane>>5), col lane&31
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wc * TN + tn) * 32 + lrow;
-        if (n >= P.N) continue;
-        int d = 0, off = 0;
-        for (int dd = 0; dd + 1 < P.ndst; ++dd)
-            if (n >= off + P.dst[dd].C && d == dd) {
-                off += P.dst[dd].C;
-                d = dd + 1;
-            }
-        const GDst &D = P.dst[d];
-        const int c = n - off;
-        const float bias = P.bias ? P.bias[n] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int rbase = (wr * TM + tm) * 32 + 4 * (lane >> 5);
-            if (!P.quad) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = rbase + (reg & 3) + 8 * (reg >> 2);
-                    if (m0 + row >= P.M) continue;
-                    const int oy = (rowY[row] + pad_y) >> sshift, ox = (rowX[row] + pad_x) >> sshift;
-                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)oy * D.sy +
-                                     (size_t)ox * D.sx + (size_t)c * D.sc + phy * D.ph_y +
-                                     phx * D.ph_x;
-                    float v = acc[tm][tn][reg] + bias;
-                    if (D.addend) v += D.addend[o];
-                    if (D.addend2) v += D.addend2[o];
-                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
-                    if (P.zout) P.zout[o] = v;
-                    D.p[o] = act_fwd(v, P.act);
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row = rbase + 8 * g;
-                    if (m0 + row >= P.M) continue;
-                    const int y = (rowY[row] + pad_y) >> 1, x = (rowX[row] + pad_x) >> 1;
-                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)y * D.sy +
-                                     (size_t)x * D.sx + (size_t)c * D.sc;
-                    float v = (acc[tm][tn][4 * g] + acc[tm][tn][4 * g + 1]) +
-                              (acc[tm][tn][4 * g + 2] + acc[tm][tn][4 * g + 3]) + bias;
-                    if (D.addend) v += D.addend[o];
-                    if (D.addend2) v += D.addend2[o];
-                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
-                    D.p[o] = v;
-                }
-            }
-        }
-    }
+    // ---- epilogue (conv_common.h)
+    conv_epilogue<TM, TN>(P, acc, rowO, BM, n0, wr, wc, lane);
 }
 
 int count_steps(const GConvParams &P)

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     int *rowB = (int *)(smem + ROWINFO), *rowY = rowB + BM, *rowX = rowY + BM;
+    long long *rowO = (long long *)(rowX + BM);   // [3][BM] output offsets (conv_epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform values must live in SGPRs: otherwise hipcc wraps every
@@ -81,9 +82,8 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 
     for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
-        int b = 0, y = -(1 << 20), x = -(1 << 20);
+        int b = 0, y = -(1 << 20), x = -(1 << 20), oy = 0, ox = 0;
         if (m < P.M) {
-            int oy, ox;
             if (!P.quad) {
                 ox = m % P.Wo;
                 const int t = m / P.Wo;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         rowB[r] = b;
         rowY[r] = y;
         rowX[r] = x;
+        conv_row_offsets(P, rowO, BM, r, m < P.M, b, oy, ox, phy, phx);
     }
     __syncthreads();
 
@@ -372,58 +373,9 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                 for (int r = 0; r < 16; ++r) acc[a][b][r] += xch[((a * TN + b) * 16 + r) * 64 + lane];
     }
 
-    // ---- epilogue (as in gconv.hip)
-    const int sshift = P.stride - 1;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wc * TN + tn) * 32 + lrow;
-        if (n >= P.N) continue;
-        int d = 0, off = 0;
-        for (int dd = 0; dd + 1 < P.ndst; ++dd)
-            if (n >= off + P.dst[dd].C && d == dd) {
-                off += P.dst[dd].C;
-                d = dd + 1;
-            }
-        const GDst &D = P.dst[d];
-        const int c = n - off;
-        const float bias = P.bias ? P.bias[n] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int rbase = (wr * TM + tm) * 32 + 4 * (lane >> 5);
-            if (!P.quad) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = rbase + (reg & 3) + 8 * (reg >> 2);
-                    if (m0 + row >= P.M) continue;
-                    const int oy = (rowY[row] + pad_y) >> sshift, ox = (rowX[row] + pad_x) >> sshift;
-                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)oy * D.sy +
-                                     (size_t)ox * D.sx + (size_t)c * D.sc + phy * D.ph_y +
-                                     phx * D.ph_x;
-                    float v = acc[tm][tn][reg] + bias;
-                    if (D.addend) v += D.addend[o];
-                    if (D.addend2) v += D.addend2[o];
-                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
-                    if (P.zout) P.zout[o] = v;
-                    D.p[o] = act_fwd(v, P.act);
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row = rbase + 8 * g;
-                    if (m0 + row >= P.M) continue;
-                    const int y = (rowY[row] + pad_y) >> 1, x = (rowX[row] + pad_x) >> 1;
-                    const size_t o = (size_t)rowB[row] * D.sb + (size_t)y * D.sy +
-                                     (size_t)x * D.sx + (size_t)c * D.sc;
-                    float v = (acc[tm][tn][4 * g] + acc[tm][tn][4 * g + 1]) +
-                              (acc[tm][tn][4 * g + 2] + acc[tm][tn][4 * g + 3]) + bias;
-                    if (D.addend) v += D.addend[o];
-                    if (D.addend2) v += D.addend2[o];
-                    if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
-                    D.p[o] = v;
-                }
-            }
-        }
-    }
+    if (P.dbg & 1) return;
+    // ---- epilogue (conv_common.h)
+    conv_epilogue<TM, TN>(P, acc, rowO, BM, n0, wr, wc, lane);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -434,7 +386,7 @@ int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
     constexpr int PA = BM / 16, PB0 = (BN + 15) / 16, PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
-    constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * sizeof(int);
+    constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * (sizeof(int) + sizeof(long long));
     static bool attr_set = false;
     if (!attr_set) {
         DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT>,
@@ -465,8 +417,11 @@ bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_
     return true;
 }
 
-int gconv2_launch(const GConvParams &P, int tile, hipStream_t st)
+int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
 {
+    GConvParams P = P0;
+    static const int dbg = getenv("DVSOF_GCONV_DBG") ? atoi(getenv("DVSOF_GCONV_DBG")) : 0;
+    P.dbg = dbg;
     const int taps = P.ks * P.ks;
     // K depth per barrier: 32 when every vector member allows it (small tiles
     // run 1-2 waves per SIMD, where the per-slice sync cost is exposed)
@@ -485,6 +440,7 @@ int gconv2_launch(const GConvParams &P, int tile, hipStream_t st)
         if (P.src[s].flat) nflat += (taps * P.src[s].C + BK - 1) / BK;
         else nvec += taps * (P.src[s].C / (BK * ksub));
     }
+    if (dbg & 2) nvec = nvec > 1 ? 1 : nvec;
     switch (tile) {
     case 1: return launch2<2, 2, 2, 2, 1, 4>(P, nflat, nvec, st);  // 128 x 128
     case 2: return k32 ? launch2<2, 2, 2, 1, 2, 3>(P, nflat, nvec, st)

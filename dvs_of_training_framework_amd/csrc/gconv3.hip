@@ -47,6 +47,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv3_kernel(const GConvParams P, co
     const int patch_bytes = patch_kb * 1024;
     unsigned char *patch0 = smem + G3_NS * BSTAGE;
     int *rowB = (int *)(patch0 + 2 * patch_bytes), *rowY = rowB + BM, *rowX = rowY + BM;
+    long long *rowO = (long long *)(rowX + BM);   // [3][BM] output offsets (conv_epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv3_kernel(const GConvParams P, co
         rowB[r] = img;
         rowY[r] = ok ? (oy0 + ry) * P.stride - pad_y : -(1 << 20);
         rowX[r] = ok ? (ox0 + rx) * P.stride - pad_x : -(1 << 20);
+        conv_row_offsets(P, rowO, BM, r, ok, img, oy0 + ry, ox0 + rx, phy, phx);
     }
     __syncthreads();
 
@@ -353,40 +355,8 @@ __global__ __launch_bounds__(CONV_NT) void gconv3_kernel(const GConvParams P, co
 #undef G3_STEP
     }
 
-    // ---- epilogue (as in gconv2.hip, no quad rows)
-    const int sshift = P.stride - 1;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wc * TN + tn) * 32 + lrow;
-        if (n >= P.N) continue;
-        int d = 0, off = 0;
-        for (int dd = 0; dd + 1 < P.ndst; ++dd)
-            if (n >= off + P.dst[dd].C && d == dd) {
-                off += P.dst[dd].C;
-                d = dd + 1;
-            }
-        const GDst &D = P.dst[d];
-        const int c = n - off;
-        const float bias = P.bias ? P.bias[n] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int rbase = (wr * TM + tm) * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = rbase + (reg & 3) + 8 * (reg >> 2);
-                if (rowY[row] < -(1 << 19)) continue;
-                const int oy = (rowY[row] + pad_y) >> sshift, ox = (rowX[row] + pad_x) >> sshift;
-                const size_t o = (size_t)rowB[row] * D.sb + (size_t)oy * D.sy + (size_t)ox * D.sx +
-                                 (size_t)c * D.sc + phy * D.ph_y + phx * D.ph_x;
-                float v = acc[tm][tn][reg] + bias;
-                if (D.addend) v += D.addend[o];
-                if (D.addend2) v += D.addend2[o];
-                if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
-                if (P.zout) P.zout[o] = v;
-                D.p[o] = act_fwd(v, P.act);
-            }
-        }
-    }
+    // ---- epilogue (conv_common.h; no quad rows here)
+    conv_epilogue<TM, TN>(P, acc, rowO, BM, n0, wr, wc, lane);
 #endif
 }
 
@@ -419,7 +389,7 @@ bool g3_plan(const GConvParams &P, int tile, G3Plan &pl)
     const int pb = ((bmn[tile][1] + 15) / 16 + 3) / 4 * 4;
     // buffer: the patch (or the flat path's [BM][16] image) + 4 dummy KiB
     pl.patch_kb = (pl.npp > bmn[tile][0] / 16 ? pl.npp : bmn[tile][0] / 16) + 4;
-    pl.lds = (size_t)G3_NS * pb * 1024 + 2 * (size_t)pl.patch_kb * 1024 + 3 * bmn[tile][0] * sizeof(int);
+    pl.lds = (size_t)G3_NS * pb * 1024 + 2 * (size_t)pl.patch_kb * 1024 + 3 * bmn[tile][0] * (sizeof(int) + sizeof(long long));
     return pl.lds <= 160 * 1024;
 }
 
