@@ -18,6 +18,7 @@ the gradient sums and activation derivatives folded into kernel epilogues
 (no autograd graph, no cat/upsample tensors, no elementwise passes).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -155,6 +156,28 @@ class _PredictorFn(torch.autograd.Function):
         enc_l, res_l, dec_l = L[0:4], L[4:4 + 2 * NUM_RES], L[4 + 2 * NUM_RES:]
         po_res, po_dec = 8, 8 + 4 * NUM_RES
 
+        # The data-gradient chain is the critical path; every weight gradient
+        # only needs its layer's output gradient.  They run on a second HIP
+        # stream so that their split-K reduces, bias sums and small-grid tails
+        # fill the CUs the dgrad kernels leave idle.  ``keep`` holds the
+        # tensors the side stream reads until the streams are joined.
+        main = torch.cuda.current_stream(dev)
+        side = ctx.module._wgrad_stream(dev)
+        keep = []
+
+        def wgrad(desc, gz, gw, gb, unit):
+            if side is None:
+                C.conv_wgrad(desc, gz, gw, gb)
+                finish(unit)
+                return
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                C.conv_wgrad(desc, gz, gw, gb)
+                finish(unit)
+            keep.append(gz)
+
         # ---- decoder, fine to coarse
         g_x = None          # gradient w.r.t. dec[i].y from the finer stage
         g_f = gflows[3]     # total gradient of the flow of this stage
@@ -169,8 +192,7 @@ class _PredictorFn(torch.autograd.Function):
             pw, pb, pfw, pfb = (po_dec + 4 * i + j for j in range(4))
             C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
                        grads[pfw], grads[pfb], B, h, w, d.Cout)
-            C.conv_wgrad(d, gz, grads[pw], grads[pb])
-            finish(('dec', i))
+            wgrad(d, gz, grads[pw], grads[pb], ('dec', i))
             srcs = lay['srcs']
             g_in = new(srcs[0][0])
             g_e = new(srcs[1][0])
@@ -192,13 +214,11 @@ class _PredictorFn(torch.autograd.Function):
         for i in reversed(range(NUM_RES)):
             l1, l2 = res_l[2 * i], res_l[2 * i + 1]
             pw1, pb1, pw2, pb2 = (po_res + 4 * i + j for j in range(4))
-            C.conv_wgrad(l2['desc'], gs, grads[pw2], grads[pb2])
-            finish(('res', i, 2))
+            wgrad(l2['desc'], gs, grads[pw2], grads[pb2], ('res', i, 2))
             g_t = new(l1['y'])
             C.conv_dgrad(l2['desc'], wt(l2), gs,
                          [dict(p=g_t, actsrc=asrc(l1))], act)
-            C.conv_wgrad(l1['desc'], g_t, grads[pw1], grads[pb1])
-            finish(('res', i, 1))
+            wgrad(l1['desc'], g_t, grads[pw1], grads[pb1], ('res', i, 1))
             below = res_l[2 * i - 1] if i > 0 else enc_l[3]
             g_prev = new(below['y'])
             dst = dict(p=g_prev, addend=gs, actsrc=asrc(below))
@@ -210,8 +230,7 @@ class _PredictorFn(torch.autograd.Function):
         gz = gs
         for i in (3, 2, 1, 0):
             lay = enc_l[i]
-            C.conv_wgrad(lay['desc'], gz, grads[2 * i], grads[2 * i + 1])
-            finish(('enc', i))
+            wgrad(lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i))
             if i == 0:
                 break
             below = enc_l[i - 1]
@@ -220,6 +239,9 @@ class _PredictorFn(torch.autograd.Function):
                          [dict(p=g_prev, addend=g_skip[i - 1],
                                actsrc=asrc(below))], act)
             gz = g_prev
+        if side is not None:
+            main.wait_stream(side)
+        del keep
         ctx.L = None
         return (None,) * (3 + len(params))
 
@@ -261,6 +283,15 @@ class Predictor(nn.Module):
         (('enc', 3),),
         (('enc', 2), ('enc', 1), ('enc', 0)),
     )
+
+    def _wgrad_stream(self, dev):
+        """Second stream of the backward (None: DVSOF_WGRAD_STREAM=0)."""
+        if os.environ.get('DVSOF_WGRAD_STREAM', '1') == '0':
+            return None
+        if getattr(self, '_wg_stream', None) is None or \
+                self._wg_stream.device != dev:
+            self._wg_stream = torch.cuda.Stream(device=dev)
+        return self._wg_stream
 
     def _buckets(self, params):
         dev = params[0].device
