@@ -147,7 +147,7 @@ def pmc_traffic(kernel):
     return round(num / den) if den else None
 
 
-def measure_roofline(h, steps=3):
+def measure_roofline(h, step_ms, steps=3):
     """Per-launch HIP-event timing of every conv-stack launch on torch's
     current stream (= the launch stream); groups by kernel template."""
     from dvs_of_training_framework_amd import conv as C
@@ -206,6 +206,16 @@ def measure_roofline(h, steps=3):
             # decompositions change the count): the hardware-utilisation view
             'executed_tflops': round(xfl / sec / 1e12, 2),
             'executed_frac': round(xfl / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+            # whole step: conv FLOPs of one step / measured step time (a lower
+            # bound of the stack's rate: the step also voxelises, evaluates the
+            # loss and runs the optimizer)
+            'step_conv_tflops': round(total_fl / steps / step_ms / 1e9, 2),
+            'step_conv_frac': round(total_fl / steps / step_ms / 1e9 /
+                                    PEAK_F32_MATRIX_TFLOPS, 4),
+            'step_conv_executed_tflops': round(total_x / steps / step_ms / 1e9, 2),
+            # sums of per-launch durations: the backward runs weight gradients
+            # on a second stream beside the data gradients, so launches overlap
+            # and these sums exceed the wall time they cover
             'conv_stack_executed_tflops': round(total_x / total_s / 1e12, 2),
             'conv_stack_tflops': round(total_fl / total_s / 1e12, 2),
             'conv_stack_frac': round(total_fl / total_s / 1e12 /
@@ -317,7 +327,7 @@ def main():
                 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
         }
     if not a.no_roofline:
-        roof = measure_roofline(h)          # every rank runs the same steps
+        roof = measure_roofline(h, dt / a.steps * 1e3)   # every rank runs the same steps
         if rank == 0:
             out['roofline'] = roof
     if rank == 0:

@@ -299,66 +299,78 @@ int gconv_pick_tile(long long m, long long n)
 // decoder data-gradient) on the VALU: out[m][n] = sum_k A[m][k] * W[n][k] for
 // the few rows n >= n_begin of W.  Keeps them out of the MFMA problem, whose N
 // is then 128/256/512 instead of 130/258/514 (one fewer column tile, and
-// 128-wide tiles with no padding).  One wave per output pixel, lanes split K.
+// 128-wide tiles with no padding).
+// One lane per output pixel (64 consecutive pixels per workgroup); the four
+// waves split the taps, so a lane walks the channels of ONE input pixel per tap
+// (its cache line is fetched once and read 16 B at a time); the weight rows are
+// wave-uniform (scalar loads); partial sums meet in LDS in a fixed order.
 namespace {
 constexpr int FLATN_MAX = 4;
 
-__global__ __launch_bounds__(256) void gconv_flat_rows_kernel(const GConvParams P, const int n_begin,
-                                                              const int nrows)
+template <int NW>   // waves per workgroup: 16 for small M (more taps in flight per pixel)
+__global__ __launch_bounds__(64 * NW) void gconv_flat_rows_kernel(const GConvParams P, const int n_begin,
+                                                                  const int nrows)
 {
+    __shared__ float part[NW][FLATN_MAX][64];
     const int lane = threadIdx.x & 63;
-    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const GSrc &S = P.src[0];
-    const int taps = P.ks * P.ks, K = taps * S.C;
+    const int taps = P.ks * P.ks;
     const size_t wrow = (size_t)taps * P.Cin_tot;
-    // destination of row n (rows are consecutive inside the trailing dsts)
-    for (long long m = wave_id; m < P.M; m += nwaves) {
-        const int ox = (int)(m % P.Wo);
-        const long long t = m / P.Wo;
-        const int oy = (int)(t % P.Ho), b = (int)(t / P.Ho);
-        float acc[FLATN_MAX] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 4 * lane; k < K; k += 256) {
-            const int tap = k / S.C, c = k - tap * S.C;
-            const int ky = tap / P.ks, kx = tap - ky * P.ks;
-            const int Y = oy * P.stride - P.pad + ky, X = ox * P.stride - P.pad + kx;
-            if ((unsigned)Y < (unsigned)P.Hv && (unsigned)X < (unsigned)P.Wv) {
-                const f32x4 a = *(const f32x4u *)(S.p + (size_t)b * S.sb + (size_t)Y * S.sy +
-                                                  (size_t)X * S.sx + c);
+    const long long m = (long long)blockIdx.x * 64 + lane;
+    const bool pix = m < P.M;
+    const int ox = (int)(m % P.Wo);
+    const long long t = m / P.Wo;
+    const int oy = (int)(t % P.Ho), b = (int)(t / P.Ho);
+    float acc[FLATN_MAX] = {0.f, 0.f, 0.f, 0.f};
+    for (int tap = wave; tap < taps; tap += NW) {
+        const int ky = tap / P.ks, kx = tap - ky * P.ks;
+        const int Y = oy * P.stride - P.pad + ky, X = ox * P.stride - P.pad + kx;
+        const bool ok = pix & ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+        const float *ap = S.p + (ok ? (size_t)b * S.sb + (size_t)Y * S.sy + (size_t)X * S.sx : 0);
+        const float *wp = P.W + (size_t)n_begin * wrow + (size_t)tap * P.Cin_tot;
+#pragma unroll 4
+        for (int c = 0; c < S.C; c += 4) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (ok) a = *(const f32x4u *)(ap + c);
 #pragma unroll
-                for (int r = 0; r < FLATN_MAX; ++r)
-                    if (r < nrows) {
-                        const f32x4 w = *(const f32x4u *)(P.W + (size_t)(n_begin + r) * wrow +
-                                                          (size_t)tap * P.Cin_tot + c);
-                        acc[r] += a[0] * w[0] + a[1] * w[1] + a[2] * w[2] + a[3] * w[3];
-                    }
-            }
+            for (int r = 0; r < FLATN_MAX; ++r)
+                if (r < nrows) {
+                    const f32x4 w = *(const f32x4u *)(wp + (size_t)r * wrow + c);
+                    acc[r] = fmaf(a[0], w[0], acc[r]);
+                    acc[r] = fmaf(a[1], w[1], acc[r]);
+                    acc[r] = fmaf(a[2], w[2], acc[r]);
+                    acc[r] = fmaf(a[3], w[3], acc[r]);
+                }
         }
+    }
 #pragma unroll
-        for (int r = 0; r < FLATN_MAX; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
-            int d = 0, off = 0;
-            for (int dd = 0; dd + 1 < P.ndst; ++dd)
-                if (n_begin >= off + P.dst[dd].C && d == dd) {
-                    off += P.dst[dd].C;
-                    d = dd + 1;
-                }
-            for (int r = 0; r < nrows; ++r) {
-                int n = n_begin + r;
-                while (n >= off + P.dst[d].C) {
-                    off += P.dst[d].C;
-                    ++d;
-                }
-                const GDst &D = P.dst[d];
-                const size_t o = (size_t)b * D.sb + (size_t)oy * D.sy + (size_t)ox * D.sx +
-                                 (size_t)(n - off) * D.sc;
-                float v = acc[r];
-                if (D.addend) v += D.addend[o];
-                if (D.addend2) v += D.addend2[o];
-                if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
-                D.p[o] = v;
-            }
+    for (int r = 0; r < FLATN_MAX; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave != 0 || !pix) return;
+    int d = 0, off = 0;
+    for (int dd = 0; dd + 1 < P.ndst; ++dd)
+        if (n_begin >= off + P.dst[dd].C && d == dd) {
+            off += P.dst[dd].C;
+            d = dd + 1;
         }
+    for (int r = 0; r < nrows; ++r) {
+        const int n = n_begin + r;
+        while (n >= off + P.dst[d].C) {
+            off += P.dst[d].C;
+            ++d;
+        }
+        const GDst &D = P.dst[d];
+        const size_t o = (size_t)b * D.sb + (size_t)oy * D.sy + (size_t)ox * D.sx +
+                         (size_t)(n - off) * D.sc;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4)
+            v += (part[w][r][lane] + part[w + 1][r][lane]) + (part[w + 2][r][lane] + part[w + 3][r][lane]);
+        if (D.addend) v += D.addend[o];
+        if (D.addend2) v += D.addend2[o];
+        if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
+        D.p[o] = v;
     }
 }
 }  // namespace
@@ -394,10 +406,13 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
             Q.ndst = d;
             const int rc = gconv_launch(Q, tile_hint, st);
             if (rc) return rc;
-            long long nb = ((long long)P.M + 3) / 4;
-            if (nb > 2048) nb = 2048;
-            hipLaunchKernelGGL(gconv_flat_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, P, Q.N,
-                               ntrail);
+            const long long nb = ((long long)P.M + 63) / 64;
+            if (nb < 512)
+                hipLaunchKernelGGL(gconv_flat_rows_kernel<16>, dim3((unsigned)nb), dim3(1024), 0, st, P,
+                                   Q.N, ntrail);
+            else
+                hipLaunchKernelGGL(gconv_flat_rows_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, P,
+                                   Q.N, ntrail);
             DVSOF_LAUNCH_CHECK();
             return DVSOF_OK;
         }

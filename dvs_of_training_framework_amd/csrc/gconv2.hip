@@ -27,6 +27,7 @@
 // fallback for shapes this kernel does not take (see gconv2_eligible).
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -133,17 +134,23 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             b_off[t][j] = PA * 1024 + R * 64 + (((2 * j + lh) ^ ((R >> 2) & 3)) << 4);
         }
 
-    auto compute1 = [&](const unsigned char *stage) {
-        // all fragment reads of the slice are issued before the first MFMA so
-        // that only the first pair's LDS latency is exposed
-        f32x4 a[2][TM], b[2][TN];
+    // Fragments are double buffered in registers: the ds_reads of slice q+1
+    // are issued before the MFMAs of slice q, so the LDS latency (and the LDS
+    // array time of 4-8 waves reading at once after a barrier) hides behind
+    // the matrix pipe instead of stalling it once per slice.
+    f32x4 fa[2][2][TM], fb[2][2][TN];
+    auto load_frags = [&](auto bufc, const unsigned char *slice) {
+        constexpr int buf = decltype(bufc)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[j][t] = *(const f32x4 *)(stage + a_off[t][j]);
+            for (int t = 0; t < TM; ++t) fa[buf][j][t] = *(const f32x4 *)(slice + a_off[t][j]);
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[j][t] = *(const f32x4 *)(stage + b_off[t][j]);
+            for (int t = 0; t < TN; ++t) fb[buf][j][t] = *(const f32x4 *)(slice + b_off[t][j]);
         }
+    };
+    auto mfma_slice = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -153,11 +160,11 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            a[j][tm][i], b[j][tn][i], acc[tm][tn], 0, 0, 0);
+                            fa[buf][j][tm][i], fb[buf][j][tn][i], acc[tm][tn], 0, 0, 0);
     };
-    auto compute = [&](const unsigned char *stage) {
-#pragma unroll
-        for (int sub = 0; sub < KPW; ++sub) compute1(stage + (sub + wgrp * KPW) * SUB);
+    auto compute1 = [&](const unsigned char *stage) {   // synchronous form (flat members)
+        load_frags(std::integral_constant<int, 0>{}, stage);
+        mfma_slice(std::integral_constant<int, 0>{});
     };
 
     // ------------------------------------------------------------------
@@ -324,29 +331,50 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             }
         };
 
-        // prologue: NS-1 slices in flight
+        // prologue: every ring slot in flight, then stage 0's fragments
+        static_assert((NS * KPW) % 2 == 0, "static fragment-buffer parity");
 #pragma unroll
-        for (int u = 0; u < NS - 1; ++u)
+        for (int u = 0; u < NS; ++u)
             if (u < nvec) issue(u);
+        if (nvec >= NS) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * LPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        load_frags(std::integral_constant<int, 0>{}, smem + wgrp * KPW * SUB);
 
         for (int s0 = 0; s0 < nvec; s0 += NS) {
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const int s = s0 + u;
                 if (s < nvec) {
-                    // slice s has landed when at most the younger slices' loads remain
-                    if (s + NS - 1 <= nvec) {
-                        if (s + NS - 2 < nvec) {
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPW) : "memory");
-                        } else {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        }
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int sub = 0; sub < KPW; ++sub) {
+                        const unsigned char *stage = smem + u * STAGE;
+                        auto step = [&](auto curc) {
+                            constexpr int cur = decltype(curc)::value;
+                            if (sub + 1 < KPW) {
+                                load_frags(std::integral_constant<int, cur ^ 1>{},
+                                           stage + (sub + 1 + wgrp * KPW) * SUB);
+                            } else if (s + 1 < nvec) {
+                                // stage s+1 has landed when at most the younger stages' loads remain
+                                if (s + NS - 1 < nvec) {
+                                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * LPW) : "memory");
+                                } else {
+                                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                                }
+                                // every wave holds its stage-s fragments in registers: slot u is free
+                                __builtin_amdgcn_s_barrier();
+                                if (s + NS < nvec) issue(u);
+                                load_frags(std::integral_constant<int, cur ^ 1>{},
+                                           smem + ((u + 1) % NS) * STAGE + wgrp * KPW * SUB);
+                            }
+                            mfma_slice(std::integral_constant<int, cur>{});
+                        };
+                        if ((u * KPW + sub) & 1) step(std::integral_constant<int, 1>{});
+                        else step(std::integral_constant<int, 0>{});
                     }
-                    __builtin_amdgcn_s_barrier();
-                    if (s + NS - 1 < nvec) issue((u + NS - 1) % NS);
-                    compute(smem + u * STAGE);
                 }
             }
         }
@@ -450,7 +478,7 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
         static const bool no8 = getenv("DVSOF_GCONV_NO_KSPLIT") != nullptr;
         const long long blocks = ((P.M + 63) / 64) * ((P.N + 63) / 64) * P.nph;
         if (k32 && !no8 && nflat == 0 && blocks <= 256)
-            return launch2<2, 2, 1, 1, 2, 4, 2>(P, nflat, nvec, st);
+            { static const int ns8 = getenv("DVSOF_NS") ? atoi(getenv("DVSOF_NS")) : 4; if (ns8 == 8) return launch2<2, 2, 1, 1, 2, 8, 2>(P, nflat, nvec, st); if (ns8 == 6) return launch2<2, 2, 1, 1, 2, 6, 2>(P, nflat, nvec, st); return launch2<2, 2, 1, 1, 2, 4, 2>(P, nflat, nvec, st); }
         return k32 ? launch2<2, 2, 1, 1, 2, 4>(P, nflat, nvec, st)
                    : launch2<2, 2, 1, 1, 1, 4>(P, nflat, nvec, st);  // 64 x 64
     }
