@@ -95,23 +95,32 @@ def conv_fwd(desc, weight, bias, device, residual=None, want_z=False):
     return y, z
 
 
-def prepare(desc, weight, want_dgrad):
+def prepare(desc, weight, want_dgrad, phase_weights=None):
     """-> (w_fwd, w_dgrad): prepared weights (dvsof_conv2d_prepare).  w_fwd is
-    the raw weight itself unless the layer runs as sub-pixel phases."""
+    the raw weight itself unless the layer runs as sub-pixel phases.
+    ``phase_weights``: the w_fwd of an earlier call -- only the data-gradient
+    form is made (from it, for a sub-pixel layer)."""
     lib = _lib.lib()
     raw = desc.Cout * desc.ksize ** 2 * sum(desc.src[i].C
                                             for i in range(desc.nsrc))
     nf = lib.dvsof_conv2d_fwd_weight_elems(ctypes.byref(desc))
-    w_fwd = weight if nf == raw else torch.empty(
-        nf, dtype=torch.float32, device=weight.device)
+    dg_only = phase_weights is not None
+    if dg_only:
+        w_fwd = phase_weights
+    else:
+        w_fwd = weight if nf == raw else torch.empty(
+            nf, dtype=torch.float32, device=weight.device)
     w_dg = torch.empty(lib.dvsof_conv2d_dgrad_weight_elems(ctypes.byref(desc)),
                        dtype=torch.float32, device=weight.device) \
         if want_dgrad else None
-    if nf != raw or want_dgrad:
+    make_fwd = not dg_only and nf != raw
+    if make_fwd or want_dgrad:
+        # sub-pixel layer, dgrad only: weight = NULL, w_fwd = the phase kernels
+        wp = None if (dg_only and nf != raw) else weight.data_ptr()
+        fp = w_fwd.data_ptr() if (nf != raw) else None
         _lib.check(lib.dvsof_conv2d_prepare(
-            ctypes.byref(desc), weight.data_ptr(),
-            None if nf == raw else w_fwd.data_ptr(), _lib.ptr(w_dg),
-            _lib.stream()), 'dvsof_conv2d_prepare')
+            ctypes.byref(desc), wp, fp, _lib.ptr(w_dg), _lib.stream()),
+            'dvsof_conv2d_prepare')
     return w_fwd, w_dg
 
 

@@ -585,14 +585,19 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
                          float *w_dgrad, void *stream)
 {
     int Ctot, Ho, Wo;
-    if (!desc_ok(d, Ctot, Ho, Wo) || !weight) return DVSOF_EINVAL;
+    if (!desc_ok(d, Ctot, Ho, Wo)) return DVSOF_EINVAL;
     hipStream_t st = as_stream(stream);
     if (is_subpixel(d)) {
         if (!w_fwd) return DVSOF_EINVAL;
-        const size_t n = (size_t)d->Cout * Ctot;
-        hipLaunchKernelGGL(subpixel_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
-                           0, st, weight, w_fwd, d->Cout, Ctot);
-        DVSOF_LAUNCH_CHECK();
+        // weight == NULL: w_fwd already holds the phase kernels (made by an
+        // earlier call); only the data-gradient form is derived from it
+        if (!weight && !w_dgrad) return DVSOF_EINVAL;
+        if (weight) {
+            const size_t n = (size_t)d->Cout * Ctot;
+            hipLaunchKernelGGL(subpixel_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)),
+                               dim3(256), 0, st, weight, w_fwd, d->Cout, Ctot);
+            DVSOF_LAUNCH_CHECK();
+        }
         if (w_dgrad) {
             dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);
             hipLaunchKernelGGL(subpixel_dgrad_weights_kernel, grid, dim3(256), 0, st,
@@ -601,6 +606,7 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
         }
         return DVSOF_OK;
     }
+    if (!weight) return DVSOF_EINVAL;
     if (is_stride2_phased(d) && w_dgrad) {
         if (w_fwd && w_fwd != weight)
             DVSOF_HIP_TRY(hipMemcpyAsync(w_fwd, weight, (size_t)d->Cout * 9 * Ctot * sizeof(float),

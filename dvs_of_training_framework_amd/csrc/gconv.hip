@@ -373,6 +373,83 @@ __global__ __launch_bounds__(64 * NW) void gconv_flat_rows_kernel(const GConvPar
         D.p[o] = v;
     }
 }
+
+// Large-M form: four lanes share one output pixel and read 64 contiguous bytes
+// of an input pixel per instruction (16 cache lines per wave-load instead of
+// 64); the weight rows sit in LDS; a wave owns 16 pixels and all taps, the four
+// lanes of a pixel meet through two shuffles (fixed order).
+constexpr int FLATQ_MAX_K = 4096;   // taps * C floats per weight row in LDS
+
+__global__ __launch_bounds__(256) void gconv_flat_rows_quad_kernel(const GConvParams P, const int n_begin,
+                                                                   const int nrows)
+{
+    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [nrows][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const GSrc &S = P.src[0];
+    const int taps = P.ks * P.ks, K = taps * S.C;
+    const size_t wrow = (size_t)taps * P.Cin_tot;
+    for (int i = threadIdx.x * 4; i < nrows * K; i += 256 * 4) {
+        const int r = i / K, k = i - r * K, tap = k / S.C, c = k - tap * S.C;
+        *(f32x4 *)(wlds + i) =
+            *(const f32x4u *)(P.W + (size_t)(n_begin + r) * wrow + (size_t)tap * P.Cin_tot + c);
+    }
+    __syncthreads();
+    const int g = lane & 3;
+    const long long m = (long long)blockIdx.x * 64 + wave * 16 + (lane >> 2);
+    const bool pix = m < P.M;
+    const int ox = (int)(m % P.Wo);
+    const long long t = m / P.Wo;
+    const int oy = (int)(t % P.Ho), b = (int)(t / P.Ho);
+    float acc[FLATN_MAX] = {0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < taps; ++tap) {
+        const int ky = tap / P.ks, kx = tap - ky * P.ks;
+        const int Y = oy * P.stride - P.pad + ky, X = ox * P.stride - P.pad + kx;
+        const bool ok = pix & ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
+        const float *ap = S.p + (ok ? (size_t)b * S.sb + (size_t)Y * S.sy + (size_t)X * S.sx : 0);
+        const float *wp = wlds + tap * S.C;
+#pragma unroll 2
+        for (int c = 4 * g; c < S.C; c += 16) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (ok) a = *(const f32x4u *)(ap + c);
+#pragma unroll
+            for (int r = 0; r < FLATN_MAX; ++r)
+                if (r < nrows) {
+                    const f32x4 w = *(const f32x4 *)(wp + r * K + c);
+                    acc[r] = fmaf(a[0], w[0], acc[r]);
+                    acc[r] = fmaf(a[1], w[1], acc[r]);
+                    acc[r] = fmaf(a[2], w[2], acc[r]);
+                    acc[r] = fmaf(a[3], w[3], acc[r]);
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FLATN_MAX; ++r) {
+        acc[r] += __shfl_xor(acc[r], 1);
+        acc[r] += __shfl_xor(acc[r], 2);
+    }
+    if (g != 0 || !pix) return;
+    int d = 0, off = 0;
+    for (int dd = 0; dd + 1 < P.ndst; ++dd)
+        if (n_begin >= off + P.dst[dd].C && d == dd) {
+            off += P.dst[dd].C;
+            d = dd + 1;
+        }
+    for (int r = 0; r < nrows; ++r) {
+        const int n = n_begin + r;
+        while (n >= off + P.dst[d].C) {
+            off += P.dst[d].C;
+            ++d;
+        }
+        const GDst &D = P.dst[d];
+        const size_t o = (size_t)b * D.sb + (size_t)oy * D.sy + (size_t)ox * D.sx +
+                         (size_t)(n - off) * D.sc;
+        float v = acc[r];
+        if (D.addend) v += D.addend[o];
+        if (D.addend2) v += D.addend2[o];
+        if (D.actsrc) v *= act_bwd(D.actsrc[o], P.bwd_act);
+        D.p[o] = v;
+    }
+}
 }  // namespace
 
 bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_bytes);
@@ -407,7 +484,11 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
             const int rc = gconv_launch(Q, tile_hint, st);
             if (rc) return rc;
             const long long nb = ((long long)P.M + 63) / 64;
-            if (nb < 512)
+            const int Kq = P.ks * P.ks * P.src[0].C;
+            if (nb >= 512 && Kq <= FLATQ_MAX_K && (P.src[0].C & 3) == 0 && ((Kq * ntrail) & 3) == 0)
+                hipLaunchKernelGGL(gconv_flat_rows_quad_kernel, dim3((unsigned)nb), dim3(256),
+                                   (size_t)ntrail * Kq * sizeof(float), st, P, Q.N, ntrail);
+            else if (nb < 512)
                 hipLaunchKernelGGL(gconv_flat_rows_kernel<16>, dim3((unsigned)nb), dim3(1024), 0, st, P,
                                    Q.N, ntrail);
             else

@@ -273,10 +273,28 @@ __global__ __launch_bounds__(256) void colsum_scalar_kernel(const float *__restr
     }
 }
 
+// Tail workgroups of the reduce kernels: dbias[c] = sum_z bias_part[z][c]
+// (the per-slab column sums wgrad2 leaves behind), fixed order.
+__device__ __forceinline__ void bias_tail(int blk, const float *__restrict__ bias_part, int nslab,
+                                          int Cout, float *__restrict__ dbias)
+{
+    const int c = blk * 256 + threadIdx.x;
+    if (c >= Cout) return;
+    float a = 0.f;
+    for (int z = 0; z < nslab; ++z) a += bias_part[(size_t)z * Cout + c];
+    dbias[c] = a;
+}
+
 // out[i] = sum_z slab[z][i], fixed order; four slabs in flight per thread
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab,
-                                                          float *__restrict__ out, size_t n, int S)
+                                                          float *__restrict__ out, size_t n, int S,
+                                                          int nb_main, const float *bias_part,
+                                                          int nslab, int Cout, float *dbias)
 {
+    if ((int)blockIdx.x >= nb_main) {
+        bias_tail(blockIdx.x - nb_main, bias_part, nslab, Cout, dbias);
+        return;
+    }
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 3 < n) {
@@ -304,30 +322,76 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 //   dW[co][ky][kx][ci] = sum over (py,a) with ky in S(py,a), (px,b) with kx in S(px,b),
 //   S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2}   (and over the K splits).
 // slab[(ph*S + s)][co][a][b][ci], ph = 2*py + px.
+// ZG threads share one output quad and split the K-split index z between them
+// (decoder layers with few output channels have tiny dW but many splits: one
+// thread per quad would walk 4*S dependent loads); partial sums meet in LDS in
+// the fixed order zg = 0..ZG-1.
+template <int ZG>
 __global__ __launch_bounds__(256) void subpixel_fold_kernel(const float *__restrict__ slab,
                                                             float *__restrict__ dW, int Cout,
-                                                            int Ctot, int S)
+                                                            int Ctot, int S, int nb_main,
+                                                            const float *bias_part, int nslab,
+                                                            float *dbias)
 {
-    const size_t n = (size_t)Cout * 9 * Ctot;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int ci = (int)(i % Ctot);
-    const int tap = (int)((i / Ctot) % 9), co = (int)(i / ((size_t)9 * Ctot));
+    constexpr int QPB = 256 / ZG;          // quads per workgroup
+    __shared__ f32x4 red[ZG > 1 ? 256 : 1];
+    if ((int)blockIdx.x >= nb_main) {
+        bias_tail(blockIdx.x - nb_main, bias_part, nslab, Cout, dbias);
+        return;
+    }
+    // one quad per (co, tap, 4 consecutive ci)
+    const int Q = (Ctot + 3) >> 2;
+    const int ql = threadIdx.x % QPB, zg = threadIdx.x / QPB;
+    const size_t idx = (size_t)blockIdx.x * QPB + ql;
+    const bool live = idx < (size_t)Cout * 9 * Q;
+    const int ci = (int)(idx % Q) * 4;
+    const int tap = (int)((idx / Q) % 9), co = (int)(idx / ((size_t)9 * Q));
     const int ky = tap / 3, kx = tap - 3 * ky;
-    // contributors (phase bit, tap bit) per kernel row/column index
-    const int pa[3][2][2] = {{{0, 0}, {1, 0}}, {{0, 1}, {1, 0}}, {{0, 1}, {1, 1}}};
     const size_t wsize = (size_t)Cout * 4 * Ctot;
-    float acc = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int py = pa[ky][u][0], a = pa[ky][u][1], px = pa[kx][v][0], b = pa[kx][v][1];
-            const size_t off = ((size_t)co * 4 + a * 2 + b) * Ctot + ci;
-            const float *sl = slab + (size_t)(2 * py + px) * S * wsize + off;
-            for (int z = 0; z < S; ++z) acc += sl[(size_t)z * wsize];
-        }
-    dW[i] = acc;
+    const int cnt = Ctot - ci;          // >= 1; static lane indices only (no scratch)
+    const bool full = cnt >= 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // contributors of kernel index k along one axis: (phase bit, tap bit)
+    //   k=0: (0,0),(1,0)   k=1: (0,1),(1,0)   k=2: (0,1),(1,1)
+    const int py0 = 0, a0 = ky > 0, py1 = 1, a1 = ky == 2;
+    const int px0 = 0, b0 = kx > 0, px1 = 1, b1 = kx == 2;
+#define FOLD_ADD(PY, A, PX, B)                                                              \
+    {                                                                                       \
+        const float *sl = slab + (size_t)(2 * (PY) + (PX)) * S * wsize +                    \
+                          ((size_t)co * 4 + (A) * 2 + (B)) * Ctot + ci;                     \
+        if (full) {                                                                         \
+            for (int z = zg; z < S; z += ZG) acc += *(const f32x4u *)(sl + (size_t)z * wsize); \
+        } else {                                                                            \
+            for (int z = zg; z < S; z += ZG) {                                              \
+                const float *q = sl + (size_t)z * wsize;                                    \
+                acc[0] += q[0];                                                             \
+                if (cnt > 1) acc[1] += q[1];                                                \
+                if (cnt > 2) acc[2] += q[2];                                                \
+            }                                                                               \
+        }                                                                                   \
+    }
+    if (live) {
+        FOLD_ADD(py0, a0, px0, b0)
+        FOLD_ADD(py0, a0, px1, b1)
+        FOLD_ADD(py1, a1, px0, b0)
+        FOLD_ADD(py1, a1, px1, b1)
+    }
+#undef FOLD_ADD
+    if (ZG > 1) {
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (zg != 0) return;
+        for (int k = 1; k < ZG; ++k) acc += red[k * QPB + ql];
+    }
+    if (!live) return;
+    float *o = dW + ((size_t)co * 9 + tap) * Ctot + ci;
+    if (full) {
+        *(f32x4u *)o = acc;
+    } else {
+        o[0] = acc[0];
+        if (cnt > 1) o[1] = acc[1];
+        if (cnt > 2) o[2] = acc[2];
+    }
 }
 
 // ---- weight gradient of "flat" concat members (2-channel flow, 5-bin voxel
@@ -343,7 +407,9 @@ constexpr int FLAT_PIX = 64;   // pixels staged per round
 template <int NCOL>
 __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *__restrict__ part)
 {
-    __shared__ float xs[FLAT_PIX][NCOL + 1];
+    constexpr int C = NCOL / 9;              // 3x3 taps (flat_ncol_ok)
+    constexpr int NC4 = (NCOL + 3) / 4 * 4;  // row stride: b128 reads
+    __shared__ __attribute__((aligned(16))) float xs[FLAT_PIX][NC4];
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const int G = P.Cout < 256 ? P.Cout : 256;      // channel lanes
@@ -352,30 +418,41 @@ __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *
     const long long per = ((long long)P.M + gridDim.x - 1) / gridDim.x;
     const long long p0 = (long long)blockIdx.x * per;
     const long long p1 = p0 + per < P.M ? p0 + per : P.M;
+    // staging role: pixel sp of the round, columns sg, sg+4, ... (tap and
+    // channel of a column are compile-time constants)
+    const int sp = tid & (FLAT_PIX - 1), sg = tid >> 6;
+    if (tid < FLAT_PIX)
+        for (int i = NCOL; i < NC4; ++i) xs[tid][i] = 0.f;
     for (int cbase = 0; cbase < P.Cout; cbase += G) {
-        float acc[NCOL];
+        float acc[NC4];
 #pragma unroll
-        for (int i = 0; i < NCOL; ++i) acc[i] = 0.f;
+        for (int i = 0; i < NC4; ++i) acc[i] = 0.f;
         for (long long base = p0; base < p1; base += FLAT_PIX) {
             __syncthreads();
-            for (int e = tid; e < FLAT_PIX * NCOL; e += 256) {
-                const int p = e / NCOL, col = e - p * NCOL;
-                const long long pix = base + p;
-                float v = 0.f;
-                if (pix < p1) {
-                    const int ox = (int)(pix % P.Wo);
-                    const long long t = pix / P.Wo;
-                    const int oy = (int)(t % P.Ho), b = (int)(t / P.Ho);
-                    const int tap = col / P.S.C, c = col - tap * P.S.C;
-                    const int ky = tap / P.ks, kx = tap - ky * P.ks;
-                    const int Y = oy * P.stride - P.pad + ky, X = ox * P.stride - P.pad + kx;
-                    if ((unsigned)Y < (unsigned)P.Hv && (unsigned)X < (unsigned)P.Wv) {
-                        const int ys = P.up ? Y >> 1 : Y, xsrc = P.up ? X >> 1 : X;
-                        v = P.S.p[(size_t)b * P.S.sb + (size_t)ys * P.S.sy + (size_t)xsrc * P.S.sx +
-                                  (size_t)c * P.S.sc];
+            {
+                const long long pix = base + sp;
+                const bool pok = pix < p1;
+                const int ox = (int)(pix % P.Wo);
+                const long long t = pix / P.Wo;
+                const int oy = (int)(t % P.Ho), b = (int)(t / P.Ho);
+                const int Y0 = oy * P.stride - P.pad, X0 = ox * P.stride - P.pad;
+                const float *sb = P.S.p + (size_t)b * P.S.sb;
+#pragma unroll
+                for (int j = 0; j < (NCOL + 3) / 4; ++j) {
+                    const int col = sg + 4 * j;     // sg < 4: col < NCOL checked below
+                    float v = 0.f;
+                    if (col < NCOL) {
+                        // tap/c from col: small runtime div on constants C (folds per sg value)
+                        const int tap = col / C, c = col - tap * C;
+                        const int ky = tap / 3, kx = tap - 3 * ky;
+                        const int Y = Y0 + ky, X = X0 + kx;
+                        if (pok && (unsigned)Y < (unsigned)P.Hv && (unsigned)X < (unsigned)P.Wv) {
+                            const int ys = P.up ? Y >> 1 : Y, xsrc = P.up ? X >> 1 : X;
+                            v = sb[(size_t)ys * P.S.sy + (size_t)xsrc * P.S.sx + (size_t)c * P.S.sc];
+                        }
+                        xs[sp][col] = v;
                     }
                 }
-                xs[p][col] = v;
             }
             __syncthreads();
             if (pl < RP && cbase + cl < P.Cout) {
@@ -383,7 +460,13 @@ __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *
                 for (int p = pl; p < np; p += RP) {
                     const float g = P.gout[(size_t)(base + p) * P.Cout + cbase + cl];
 #pragma unroll
-                    for (int i = 0; i < NCOL; ++i) acc[i] = fmaf(g, xs[p][i], acc[i]);
+                    for (int i = 0; i < NC4; i += 4) {
+                        const f32x4 x = *(const f32x4 *)&xs[p][i];
+                        acc[i] = fmaf(g, x[0], acc[i]);
+                        acc[i + 1] = fmaf(g, x[1], acc[i + 1]);
+                        acc[i + 2] = fmaf(g, x[2], acc[i + 2]);
+                        acc[i + 3] = fmaf(g, x[3], acc[i + 3]);
+                    }
                 }
             }
         }
@@ -555,7 +638,8 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
     if (need + wgrad_flat_workspace_floats(flat, nflat) > ws_floats) return DVSOF_ENOSPACE;
     P.klen = (((P.M + S - 1) / S) + BK - 1) / BK * BK;
     P.dW = direct ? dW : ws;
-    P.dbias = nullptr;   // bias gradient: separate column-sum pass below
+    P.dbias = nullptr;
+    float *bias_part = ws + (direct ? 0 : (size_t)nslab * wsize);   // [nslab][Cout] or colsum partials
     static const bool force_v1 = getenv("DVSOF_WGRAD_V1") != nullptr;
     // flat members: dedicated VALU kernel when every one of them qualifies
     bool flat_valu = nflat > 0 && !force_v1;
@@ -564,11 +648,20 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
     for (int s = 0; s < P.nsrc; ++s) any_vec = any_vec || !P.src[s].flat;
     int want_flat = -1;  // v1 MFMA tiles for everything ...
     int rc = DVSOF_OK;
+    bool bias_in_kernel = false;
     if (!force_v1 && wgrad2_eligible(P)) {  // ... or v2 for the vector members
         int bm, bn;
         tile_dims(tile, bm, bn);
         const int nt = enumerate_tiles(P, bn, 0);
-        if (nt > 0) rc = wgrad2_launch(P, tile, nt, st);
+        if (nt > 0) {
+            // v2 also leaves the bias gradient: per-slab column sums of gout
+            if (dbias) {
+                P.dbias = direct ? dbias : bias_part;
+                bias_in_kernel = true;
+            }
+            rc = wgrad2_launch(P, tile, nt, st);
+            P.dbias = nullptr;
+        }
         if (rc) return rc;
         want_flat = 1;
     } else if (flat_valu) {
@@ -585,34 +678,50 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
         }
         if (rc) return rc;
     }
-    if (dbias) {  // column sums of gout (all phases cover gout exactly once)
+    if (dbias && !bias_in_kernel) {  // column sums of gout (all phases cover gout exactly once)
         const long long rows = (long long)P.B * (P.g_sb / P.Cout);
-        float *part = ws + (direct ? 0 : (size_t)nslab * wsize);
         const int nb = colsum_blocks(rows);
         if (P.Cout & 3)
             hipLaunchKernelGGL(colsum_scalar_kernel, dim3(nb), dim3(256), 0, st, P.gout, rows, P.Cout,
-                               part);
+                               bias_part);
         else
-            hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, P.gout, rows, P.Cout, part);
+            hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, P.gout, rows, P.Cout,
+                               bias_part);
         DVSOF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((P.Cout + 1023) / 1024)), dim3(256),
-                           0, st, (const float *)part, dbias, (size_t)P.Cout, nb);
+        const int nbm = (P.Cout + 1023) / 1024;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)nbm), dim3(256), 0, st,
+                           (const float *)bias_part, dbias, (size_t)P.Cout, nb, nbm,
+                           (const float *)nullptr, 0, 0, (float *)nullptr);
         DVSOF_LAUNCH_CHECK();
     }
+    // the bias partials of the slabs ride along with the slab reduce / fold
+    const bool bias_tail_needed = bias_in_kernel && !direct;
+    const int nb_bias = bias_tail_needed ? (P.Cout + 255) / 256 : 0;
     if (!direct && (any_vec || !flat_valu)) {
         if (P.nph == 4) {
-            const size_t n = (size_t)P.Cout * 9 * P.Cin_tot;
-            hipLaunchKernelGGL(subpixel_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                               st, (const float *)ws, dW, P.Cout, P.Cin_tot, S);
+            const size_t n = (size_t)P.Cout * 9 * ((P.Cin_tot + 3) / 4);
+            const int zg = S <= 2 ? 1 : S <= 8 ? 4 : 16;
+            const int nbm = (int)((n + 256 / zg - 1) / (256 / zg));
+            auto kern = zg == 1 ? subpixel_fold_kernel<1> : zg == 4 ? subpixel_fold_kernel<4>
+                                                                    : subpixel_fold_kernel<16>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nbm + nb_bias)), dim3(256), 0, st,
+                               (const float *)ws, dW, P.Cout, P.Cin_tot, S, nbm,
+                               (const float *)bias_part, nslab, dbias);
         } else {
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wsize + 1023) / 1024)),
-                               dim3(256), 0, st, (const float *)ws, dW, wsize, S);
+            const int nbm = (int)((wsize + 1023) / 1024);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(nbm + nb_bias)), dim3(256), 0, st,
+                               (const float *)ws, dW, wsize, S, nbm, (const float *)bias_part, nslab,
+                               P.Cout, dbias);
         }
+        DVSOF_LAUNCH_CHECK();
+    } else if (bias_tail_needed) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)nb_bias), dim3(256), 0, st,
+                           (const float *)nullptr, (float *)nullptr, (size_t)0, 0, 0,
+                           (const float *)bias_part, nslab, P.Cout, dbias);
         DVSOF_LAUNCH_CHECK();
     }
     if (flat_valu) {   // overwrites the flat members' columns of dW
-        float *part = ws + (direct ? 0 : (size_t)nslab * wsize) +
-                      (dbias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
+        float *part = bias_part + (dbias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
         for (int i = 0; i < nflat; ++i) {
             rc = flat_launch(flat[i], part, dW, st);
             if (rc) return rc;

@@ -144,6 +144,13 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lrow = lane & 31, lh = lane >> 5;
+    // Bias gradient = column sums of gout: the first column tile's wc = 0 waves
+    // add up the A fragments they read anyway (a few v_add per slice on 1/ntiles
+    // of the workgroups; replaces a separate pass over gout).
+    const bool do_bias = P.dbias != nullptr && blockIdx.x == 0 && wc == 0;
+    float bsum[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) bsum[t] = 0.f;
     // LDS byte addresses of this lane's fragment column (k parity = lh)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const unsigned a_base = lds0 + (unsigned)((lh * BMc + wr * TM * 32 + lrow) * 4);
@@ -166,6 +173,10 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
         }                                                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
         __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (do_bias) {                                                                         \
+            _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                 \
+                _Pragma("unroll") for (int t = 0; t < TM; ++t) bsum[t] += fa[q][t];            \
+        }                                                                                      \
         _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                     \
             _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                  \
                 _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] =                \
@@ -201,6 +212,14 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 #undef W2_COMPUTE
 #undef DS_READ
 
+    if (do_bias) {   // lanes l and l^32 hold the two k parities of the same channel
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32);
+            const int co = co0 + (wr * TM + t) * 32 + lrow;
+            if (lh == 0 && co < P.Cout) P.dbias[(size_t)blockIdx.z * P.Cout + co] = v;
+        }
+    }
     const size_t wsize = (size_t)P.Cout * taps * P.Cin_tot;
     float *dW = P.dW + (size_t)blockIdx.z * wsize;
 #pragma unroll

@@ -94,6 +94,15 @@ class _PredictorFn(torch.autograd.Function):
         dec = [(p[o + 4 * i], p[o + 4 * i + 1], p[o + 4 * i + 2],
                 p[o + 4 * i + 3]) for i in range(4)]
         L = []          # per conv layer: dict(desc, y, z, srcs)
+        # data-gradient forms of the weights are only needed by the backward:
+        # they are made on the second stream while the forward runs.  That
+        # stream first waits for everything enqueued so far (the optimizer's
+        # update of the weights; the previous backward's readers of the
+        # buffers it is about to reuse).
+        main = torch.cuda.current_stream(dev)
+        side = module._wgrad_stream(dev) if want_grad else None
+        if side is not None:
+            side.wait_stream(main)
 
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
@@ -101,7 +110,18 @@ class _PredictorFn(torch.autograd.Function):
             # prepared weights: sub-pixel phase kernels for the decoder, and
             # (when training) the data-gradient form, made once per step
             first = len(L) == 0       # voxel input needs no data gradient
-            w_fwd, w_dg = C.prepare(d, _phys(wgt), want_grad and not first)
+            need_dg = want_grad and not first
+            if side is not None and need_dg:
+                w_fwd, _ = C.prepare(d, _phys(wgt), False)
+                if w_fwd is not wgt:          # phase kernels: made on main
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    _, w_dg = C.prepare(d, _phys(wgt), True,
+                                        phase_weights=w_fwd)
+            else:
+                w_fwd, w_dg = C.prepare(d, _phys(wgt), need_dg)
             y, z = C.conv_fwd(d, w_fwd, bias, dev, residual, mish)
             L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg))
             return y
@@ -130,6 +150,10 @@ class _PredictorFn(torch.autograd.Function):
             f = C.head_fwd(x, dec[i][2], dec[i][3], B, h, w, cx)
             flows.append(f)
         if want_grad:
+            ctx.dg_ready = None
+            if side is not None:
+                ctx.dg_ready = torch.cuda.Event()
+                ctx.dg_ready.record(side)
             ctx.L, ctx.act, ctx.dims = L, act, (B, Cin, H, W)
             ctx.params = params
             ctx.module = module
@@ -163,6 +187,8 @@ class _PredictorFn(torch.autograd.Function):
         # tensors the side stream reads until the streams are joined.
         main = torch.cuda.current_stream(dev)
         side = ctx.module._wgrad_stream(dev)
+        if ctx.dg_ready is not None:
+            main.wait_event(ctx.dg_ready)
         keep = []
 
         def wgrad(desc, gz, gw, gb, unit):

@@ -212,6 +212,9 @@ typedef struct {
  * dvsof_conv2d_prepare fills w_fwd (may be NULL when
  * dvsof_conv2d_fwd_weight_elems == Cout*k*k*Ctot: forward then takes the raw
  * weights) and w_dgrad (may be NULL) from the raw [Cout][k][k][Ctot] weights.
+ * For a sub-pixel layer, weight == NULL means "w_fwd already holds the phase
+ * kernels of an earlier call": only w_dgrad is derived from them (lets a
+ * caller make the data-gradient form later, e.g. on another stream).
  */
 size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *desc);
 size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *desc);
