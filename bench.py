@@ -115,14 +115,11 @@ def conv_flops(desc, kind):
 
 def executed_flops(desc, kind):
     """FLOPs the MFMA kernels actually issue: the sub-pixel decomposition of
-    upsample+3x3 runs 16 instead of 36 tap-products; the phased stride-2 data
-    gradient runs 16 (4 of them on zero weights) instead of 9."""
+    upsample+3x3 runs 16 instead of 36 tap-products (the phased stride-2 data
+    gradient runs exactly its 9: phase (py,px) has (1+py)(1+px) taps)."""
     f = conv_flops(desc, kind)
     if desc.upsample and desc.ksize == 3 and desc.pad == 1:
         return f * 16.0 / 36.0
-    if kind == 1 and desc.stride == 2 and desc.ksize == 3 and not desc.upsample \
-            and desc.H % 2 == 0 and desc.W % 2 == 0:
-        return f * 16.0 / 9.0
     return f
 
 

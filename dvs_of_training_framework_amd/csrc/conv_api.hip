@@ -506,6 +506,7 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         P.stride = 1;
         P.pad = 0;
         P.nph = 4;
+        P.ph_exact = 1;
         P.w_phase_stride = (long long)Ctot * 4 * d->Cout;
         for (int i = 0; i < d->nsrc; ++i) {
             P.dst[i].ph_y = P.dst[i].sy;

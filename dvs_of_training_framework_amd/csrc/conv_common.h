@@ -56,6 +56,8 @@ struct GConvParams {
     int quad;           // rows ordered (b,y,x,dy,dx); epilogue sums the 2x2 quad
     int act;            // forward activation (ACT_*), applied after bias+addend
     int bwd_act;        // activation kind for actsrc
+    int ph_exact;       // phased stride-2 dgrad: phase (py,px) only has (1+py) x (1+px) non-zero
+                        // taps; a kernel MAY skip the others (they multiply zero weights)
     int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step
 };
 

@@ -44,7 +44,7 @@ struct KIt {
 // workgroup per CU), the two accumulator sets are added through LDS at the end.
 template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT>
 __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvParams P,
-                                                                 const int nflat, const int nvec)
+                                                                 const int nflat, const int nvec_all)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins/types below
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
@@ -76,8 +76,11 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int taps = P.ks * P.ks;
-    const int ph = blockIdx.z, phy = ph >> 1, phx = ph & 1;
+    // exact-tap phases differ 4x in work: the heavy ones are dispatched first
+    const int ph = P.ph_exact ? 3 - (int)blockIdx.z : (int)blockIdx.z, phy = ph >> 1, phx = ph & 1;
+    const int kh = P.ph_exact ? 1 + phy : P.ks, kw = P.ph_exact ? 1 + phx : P.ks;
     const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
+    const int nvec = P.ph_exact ? nvec_all / (P.ks * P.ks) * (kh * kw) : nvec_all;
     const float *Wp = P.W + (size_t)ph * P.w_phase_stride;
     const size_t wrow = (size_t)taps * P.Cin_tot;
 
@@ -308,9 +311,9 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             if (it_c0 >= it_C) {
                 it_c0 = 0;
                 new_tap = true;
-                if (++it_kx == P.ks) {
+                if (++it_kx == kw) {
                     it_kx = 0;
-                    if (++it_ky == P.ks) {
+                    if (++it_ky == kh) {
                         it_ky = 0;
                         it_coff += it_C;
                         ++it_s;
@@ -469,6 +472,7 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
         else nvec += taps * (P.src[s].C / (BK * ksub));
     }
     if (dbg & 2) nvec = nvec > 1 ? 1 : nvec;
+    if (nflat > 0 || getenv("DVSOF_NO_PH_EXACT")) P.ph_exact = 0;
     switch (tile) {
     case 1: return launch2<2, 2, 2, 2, 1, 4>(P, nflat, nvec, st);  // 128 x 128
     case 2: return k32 ? launch2<2, 2, 2, 1, 2, 3>(P, nflat, nvec, st)
