@@ -568,14 +568,24 @@ void tile_dims(int tile, int &bm, int &bn)
     }
 }
 
-// (tile, K splits): the largest tile that reaches >= 512 workgroups (2 per CU)
-// with at most 2 K splits; K splits cost a slab write + read of |dW| each.
+// (tile, K splits) by a small occupancy model.  A CU runs `slots` workgroups of a
+// tile at once (LDS ring footprint); workgroups are dealt round-robin to 256
+// CUs, so the launch ends when the fullest CU has worked through its k blocks:
+//   g(k) = full rounds of `slots` blocks + the last partial round, where a lone
+//   block on a CU only reaches ~80 % of the matrix rate.
+// Cost = (K steps per block + fixed prologue/epilogue) * g * step time / tile
+// efficiency + the slab write/read when there is more than one slab.
+// (Residual layers, 144 tiles of 128x128: S=4 -> 576 blocks on 512 slots ran
+// 123 us, S=3 -> 432 blocks 105 us.)
 int pick_tile_and_splits(const WGradParams &P, int *S_out)
 {
     const int taps = P.ks * P.ks;
-    static const int cand[5] = {1, 4, 3, 5, 2};   // by preference
+    static const int cand[5] = {1, 4, 3, 5, 2};
+    static const int slots_of[6] = {0, 2, 3, 5, 3, 3};          // by tile id
+    static const double eff_of[6] = {0, 0.85, 0.80, 0.70, 0.80, 0.65};
     int best = -1, bestS = 1;
     double best_cost = 1e300;
+    const long long ksteps = (P.M + BK - 1) / BK;
     for (int i = 0; i < 5; ++i) {
         int bm, bn;
         tile_dims(cand[i], bm, bn);
@@ -587,22 +597,26 @@ int pick_tile_and_splits(const WGradParams &P, int *S_out)
             for (int s = 0; s < P.nsrc; ++s) tiles += (taps * P.src[s].C + bn - 1) / bn;
         const long long rows = (P.Cout + bm - 1) / bm;
         tiles *= rows * P.nph;
-        int S = (int)((512 + tiles - 1) / tiles);
-        const int maxS = (P.M + 511) / 512;              // >= 32 K slices per split
-        if (S > maxS) S = maxS;
-        if (S < 1) S = 1;
-        if (S > 64) S = 64;
-        // cost model: padded MFMA work / tile efficiency + slab traffic
-        const double eff = (bm * bn >= 128 * 128) ? 1.0 : (bm * bn >= 64 * 128) ? 0.85 : 0.7;
-        double work = (double)tiles * bm * bn * P.M / eff;              // MACs
-        const double blocks = (double)tiles * S;
-        if (blocks < 512) work *= 512.0 / blocks;
-        const double slab = (S * P.nph > 1) ? 2.0 * S * P.nph * P.Cout * taps * P.Cin_tot * 4.0 : 0.0;
-        const double cost = work / 70e12 * 2.0 + slab / 3e12;           // seconds (rough)
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = cand[i];
-            bestS = S;
+        const int slots = slots_of[cand[i]];
+        const double step_us = 2.0 * bm * bn * BK / (157.3e12 / 256) * 1e6 / eff_of[cand[i]];
+        int maxS = (int)((P.M + 511) / 512);              // >= 32 K steps per split
+        if (maxS > 64) maxS = 64;
+        if (maxS < 1) maxS = 1;
+        for (int S = 1; S <= maxS; ++S) {
+            const long long blocks = tiles * S;
+            const long long kmax = (blocks + 255) / 256;  // blocks on the fullest CU
+            const long long full = kmax / slots, r = kmax % slots;
+            const double g = (double)full * slots + (r == 1 ? 1.25 : (double)r);
+            const double steps = (double)((ksteps + S - 1) / S) + 4.0;
+            const double slab = (S * P.nph > 1)
+                                    ? 2.0 * S * P.nph * P.Cout * taps * (double)P.Cin_tot * 4.0 / 4e6
+                                    : 0.0;                 // us at ~4 TB/s
+            const double cost = steps * g * step_us + slab;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = cand[i];
+                bestS = S;
+            }
         }
     }
     if (S_out) *S_out = bestS;
