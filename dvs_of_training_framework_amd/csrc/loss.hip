@@ -14,6 +14,7 @@
 // a single-workgroup finalize kernel adds the records in a fixed order
 // (bitwise reproducible, no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,6 +40,8 @@ struct Params {
     const int32_t *start, *stop;
     float *partials;
     int32_t *oob;               // [K*N]
+    double *group;              // [K*N][NGROUP] finalize stage records
+    int *counter;               // finalize arrival counter (zeroed by the main kernel)
     const float *seeds_dev;     // [3*K] or null
     float seeds_host[3];        // used when seeds_dev == null
 };
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
+    if (FWD && bid == 0 && tid == 0 && P.counter) *P.counter = 0;
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -225,10 +229,9 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 
 // Per-sample out-of-border pixel counts (utils/loss.py:101) ahead of the
 // fused forward+backward sweep.  Integer atomics: order-independent.
-__global__ __launch_bounds__(NT) void loss_count_oob_kernel(const Params P)
+__device__ __forceinline__ void count_oob_block(const Params &P, int bid, int *red)
 {
-    __shared__ int red[NT / kWave];
-    const int tid = threadIdx.x, bid = blockIdx.x;
+    const int tid = threadIdx.x;
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -259,71 +262,189 @@ __global__ __launch_bounds__(NT) void loss_count_oob_kernel(const Params P)
     }
 }
 
-// One workgroup adds the per-tile records in a fixed order (double) and applies
-// the reference's normalisers.  terms[t*K + k], t = smooth/photo/border.
-// Work items (scale k, sample n) and (scale k, sum i) are dealt to the 4 waves;
-// each is a lane-strided sum + shuffle tree, so there are only two barriers.
-__global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, float *terms,
-                                                           float *loss_out, float w0,
-                                                           float w1, float w2,
-                                                           float loss_scale, int write_oob)
+__global__ __launch_bounds__(NT) void loss_count_oob_kernel(const Params P)
 {
-    __shared__ double s_sum[DVSOF_MAX_SCALES][5];
-    __shared__ double s_border[DVSOF_MAX_SCALES][64];   // per (scale, sample slot)
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    constexpr int NW = NT / kWave;
-    // (k, i): global sums of photo and the four smoothness directions
-    for (int item = wave; item < P.K * 5; item += NW) {
-        const int k = item / 5, i = item - 5 * k;
-        const ScaleDev &S = P.s[k];
-        const float *part = P.partials + (size_t)S.block_begin * NPART;
-        const int nb = P.N * S.tiles_per_sample;
-        double a = 0;
-        for (int b = lane; b < nb; b += kWave) a += (double)part[(size_t)b * NPART + i];
-        a = wave_sum(a);
-        if (lane == 0) s_sum[k][i] = a;
+    __shared__ int red[NT / kWave];
+    count_oob_block(P, blockIdx.x, red);
+}
+
+// ---------------------------------------------------------------------------
+// The whole cascaded frame pyramid (utils/loss.py:207-210: level k resamples
+// level k-1, level 0 resamples the input frames) in ONE launch.  A workgroup
+// owns a 16x64 tile of the finest level of one frame and recomputes, level by
+// level in LDS, the (small) regions of the coarser levels that tile depends
+// on -- the arithmetic per pixel is exactly resize_bilinear_ac_kernel's, so the
+// values are bitwise those of K dependent launches.  Coarser-level pixels are
+// written by the first tile (in y, then x) whose region contains them.
+// Needs non-decreasing level sizes: then every pixel of level k-1 is a tap of
+// some pixel of level k, so the regions of all tiles cover each level.
+// Trailing workgroups of the same launch count out-of-border pixels.
+// ---------------------------------------------------------------------------
+constexpr int PYR_MAXR = 1536;   // floats per staged region
+
+struct PyrParams {
+    const float *src;
+    float *lev[DVSOF_MAX_SCALES];
+    int h[DVSOF_MAX_SCALES], w[DVSOF_MAX_SCALES];
+    float sh[DVSOF_MAX_SCALES], sw[DVSOF_MAX_SCALES];   // input step per output pixel
+    int K, D, H, W;
+    int tiles_x, tiles_per_frame, nblocks;
+};
+
+__device__ __forceinline__ int pyr_lo(float s, int o) { return (int)(s * (float)o); }
+__device__ __forceinline__ int pyr_hi(float s, int o, int nin)
+{
+    const int y0 = min((int)(s * (float)o), nin - 1);
+    return y0 + (y0 < nin - 1 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, const Params P,
+                                                          const int do_count)
+{
+    __shared__ float buf[2][PYR_MAXR];
+    __shared__ int red[NT / kWave];
+    if ((int)blockIdx.x >= Q.nblocks) {
+        if (do_count) count_oob_block(P, blockIdx.x - Q.nblocks, red);
+        return;
     }
-    // (k, n): border sum / count of one sample; partial border per wave slot
-    for (int k = 0; k < P.K; ++k)
-        if (tid < 64) s_border[k][tid] = 0;
+    const int tid = threadIdx.x, K = Q.K;
+    const int d = blockIdx.x / Q.tiles_per_frame;
+    const int t = blockIdx.x - d * Q.tiles_per_frame;
+    const int ty = t / Q.tiles_x, tx = t - ty * Q.tiles_x;
+    // regions [y0,y1] x [x0,x1] per level, and the previous tile's region end.
+    // All loops are unrolled over DVSOF_MAX_SCALES with static indices (runtime
+    // indexing would put these arrays in scratch memory).
+    int ry0[DVSOF_MAX_SCALES], ry1[DVSOF_MAX_SCALES], rx0[DVSOF_MAX_SCALES], rx1[DVSOF_MAX_SCALES];
+    int pey[DVSOF_MAX_SCALES], pex[DVSOF_MAX_SCALES];   // -1: no previous tile
+#pragma unroll
+    for (int k = DVSOF_MAX_SCALES - 1; k >= 0; --k) {
+        ry0[k] = ry1[k] = rx0[k] = rx1[k] = 0;
+        pey[k] = pex[k] = -1;
+        if (k == K - 1) {
+            ry0[k] = ty * TH;
+            ry1[k] = min(ry0[k] + TH - 1, Q.h[k] - 1);
+            rx0[k] = tx * TW;
+            rx1[k] = min(rx0[k] + TW - 1, Q.w[k] - 1);
+            pey[k] = ty * TH - 1;
+            pex[k] = tx * TW - 1;
+        } else if (k < K - 1) {
+            ry0[k] = pyr_lo(Q.sh[k + 1], ry0[k + 1]);
+            ry1[k] = pyr_hi(Q.sh[k + 1], ry1[k + 1], Q.h[k]);
+            rx0[k] = pyr_lo(Q.sw[k + 1], rx0[k + 1]);
+            rx1[k] = pyr_hi(Q.sw[k + 1], rx1[k + 1], Q.w[k]);
+            pey[k] = pey[k + 1] < 0 ? -1 : pyr_hi(Q.sh[k + 1], pey[k + 1], Q.h[k]);
+            pex[k] = pex[k + 1] < 0 ? -1 : pyr_hi(Q.sw[k + 1], pex[k + 1], Q.w[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DVSOF_MAX_SCALES; ++k) {
+        if (k >= K) break;
+        const int km = k > 0 ? k - 1 : 0;
+        const int hin = k ? Q.h[km] : Q.H, win = k ? Q.w[km] : Q.W;
+        const int rh = ry1[k] - ry0[k] + 1, rw = rx1[k] - rx0[k] + 1;
+        const float *in = k ? buf[km & 1] : Q.src + (size_t)d * Q.H * Q.W;
+        const int iy0 = k ? ry0[km] : 0, ix0 = k ? rx0[km] : 0;
+        const int ipitch = k ? rx1[km] - rx0[km] + 1 : Q.W;
+        float *cur = buf[k & 1];
+        float *out = Q.lev[k] + (size_t)d * Q.h[k] * Q.w[k];
+        const float sh = Q.sh[k], sw = Q.sw[k];
+        for (int i = tid; i < rh * rw; i += NT) {
+            const int ly = i / rw, lx = i - ly * rw;
+            const int y = ry0[k] + ly, x = rx0[k] + lx;
+            const float fy = sh * (float)y, fx = sw * (float)x;
+            const int y0 = min((int)fy, hin - 1), x0 = min((int)fx, win - 1);
+            const int y1 = y0 + (y0 < hin - 1 ? 1 : 0), x1 = x0 + (x0 < win - 1 ? 1 : 0);
+            const float wy = fy - (float)y0, wx = fx - (float)x0, hy = 1.f - wy, hx = 1.f - wx;
+            const float *r0 = in + (size_t)(y0 - iy0) * ipitch - ix0;
+            const float *r1 = in + (size_t)(y1 - iy0) * ipitch - ix0;
+            const float v = hy * (hx * r0[x0] + wx * r0[x1]) + wy * (hx * r1[x0] + wx * r1[x1]);
+            if (k + 1 < K) cur[i] = v;
+            if (y > pey[k] && x > pex[k]) out[(size_t)y * Q.w[k] + x] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// Finalize: workgroup (k, n) adds the tile records of sample n at scale k in a
+// fixed order (double) into one group record; the LAST workgroup to finish
+// (fence + counter, the standard fence-reduction pattern) adds the group
+// records in a fixed order, applies the reference's normalisers and writes
+// terms[t*K + k], t = smooth/photo/border, and the combined loss.  The result
+// does not depend on which workgroup happens to be last.
+constexpr int NGROUP = 8;   // doubles per group record: 7 sums + pad
+
+__device__ __forceinline__ double block_sum(double v, double *sh, int tid)
+{
+    v = wave_sum(v);
     __syncthreads();
-    // sample n belongs to wave n % NW (64 % NW == 0: every slot n & 63 has one
-    // owner wave, which visits its samples in increasing n)
-    for (int item = 0; item < P.K * ((P.N + NW - 1) / NW); ++item) {
-        const int k = item % P.K, n = (item / P.K) * NW + wave;
-        if (n >= P.N) continue;
+    if ((tid & (kWave - 1)) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, double *group,
+                                                           int *counter, float *terms,
+                                                           float *loss_out, float w0, float w1,
+                                                           float w2, float loss_scale,
+                                                           int write_oob)
+{
+    __shared__ double sh[NT / kWave];
+    __shared__ int s_last;
+    __shared__ double s_sum[DVSOF_MAX_SCALES][6];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x / P.N, n = blockIdx.x - k * P.N;
+    {
         const ScaleDev &S = P.s[k];
         const float *part = P.partials + ((size_t)S.block_begin + (size_t)n * S.tiles_per_sample) * NPART;
-        double bs = 0, c = 0;
-        for (int b = lane; b < S.tiles_per_sample; b += kWave) {
-            bs += (double)part[(size_t)b * NPART + 5];
-            c += (double)part[(size_t)b * NPART + 6];
+        double a[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int b = tid; b < S.tiles_per_sample; b += NT) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) a[i] += (double)part[(size_t)b * NPART + i];
         }
-        bs = wave_sum(bs);
-        c = wave_sum(c);
-        if (lane == 0) {
-            // utils/loss.py:101,113 -- samples are visited in increasing n by
-            // the same wave slot, so the accumulation order is fixed
-            if (c > 0) s_border[k][n & 63] += bs / (2.0 * c * (double)P.N);
-            if (write_oob) P.oob[k * P.N + n] = (int)c;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const double v = block_sum(a[i], sh, tid);
+            if (tid == 0) group[(size_t)blockIdx.x * NGROUP + i] = v;
+            if (i == 6 && tid == 0 && write_oob) P.oob[k * P.N + n] = (int)v;
+        }
+    }
+    __threadfence();
+    if (tid == 0) s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // items (k, i): i < 5 global sums of photo + four smoothness directions,
+    // i == 5: border term = sum_n bs_n / (2 c_n N)  (utils/loss.py:101,113)
+    for (int kk = 0; kk < P.K; ++kk) {
+        double a[6] = {0, 0, 0, 0, 0, 0};
+        for (int nn = tid; nn < P.N; nn += NT) {
+            const volatile double *g = group + ((size_t)kk * P.N + nn) * NGROUP;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[i] += g[i];
+            const double bs = g[5], c = g[6];
+            if (c > 0) a[5] += bs / (2.0 * c * (double)P.N);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double v = block_sum(a[i], sh, tid);
+            if (tid == 0) s_sum[kk][i] = v;
         }
     }
     __syncthreads();
     if (tid == 0) {
         double total[3] = {0, 0, 0};
-        for (int k = 0; k < P.K; ++k) {
-            const ScaleDev &S = P.s[k];
-            const double *a = s_sum[k];
-            double border = 0;
-            for (int n = 0; n < 64; ++n) border += s_border[k][n];
+        for (int kk = 0; kk < P.K; ++kk) {
+            const ScaleDev &S = P.s[kk];
+            const double *a = s_sum[kk];
             // empty crops contribute 0 (utils/loss.py:29-30)
             const double sm = ((S.c_smooth[0] > 0 ? a[1] / S.c_smooth[0] : 0) +
                                (S.c_smooth[1] > 0 ? a[2] / S.c_smooth[1] : 0) +
                                (S.c_smooth[2] > 0 ? (a[3] + a[4]) / S.c_smooth[2] : 0)) / 4.0;
             const double ph = a[0] / ((double)P.N * S.h * S.w);
-            terms[0 * P.K + k] = (float)sm;
-            terms[1 * P.K + k] = (float)ph;
-            terms[2 * P.K + k] = (float)border;
+            const double border = a[5];
+            terms[0 * P.K + kk] = (float)sm;
+            terms[1 * P.K + kk] = (float)ph;
+            terms[2 * P.K + kk] = (float)border;
             total[0] += sm;
             total[1] += ph;
             total[2] += border;
@@ -331,6 +452,7 @@ __global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, float
         if (loss_out)  // combined_loss, utils/training.py:23
             loss_out[0] = (float)((w0 * total[0] + w1 * total[1] + w2 * total[2]) /
                                   (double)P.K * (double)loss_scale);
+        *counter = 0;   // ready for the next call on this workspace
     }
 }
 
@@ -386,6 +508,106 @@ int build_params(const dvsof_loss_scale_t *sc, int K, int N, Params &P, int &tot
     return DVSOF_OK;
 }
 
+// workspace: [partials nb*NPART f32][group K*N*NGROUP f64][counter]
+size_t ws_layout(int nb, int K, int N, size_t &group_off, size_t &counter_off)
+{
+    size_t o = (size_t)nb * NPART * sizeof(float);
+    o = (o + 15) & ~(size_t)15;
+    group_off = o;
+    o += (size_t)K * N * NGROUP * sizeof(double);
+    counter_off = o;
+    return o + 16;
+}
+
+void bind_ws(Params &P, void *ws, int nb)
+{
+    size_t g, c;
+    ws_layout(nb, P.K, P.N, g, c);
+    P.partials = (float *)ws;
+    P.group = (double *)((char *)ws + g);
+    P.counter = (int *)((char *)ws + c);
+}
+
+// Pyramid plan: fused single launch when the level sizes are non-decreasing
+// and every staged region fits PYR_MAXR; else one resize launch per level.
+bool pyramid_plan(int D, int H, int W, float *const *levels, const int *hs, const int *ws, int K,
+                  const float *images, PyrParams &Q)
+{
+    if (K < 1 || K > DVSOF_MAX_SCALES) return false;
+    Q.src = images;
+    Q.K = K;
+    Q.D = D;
+    Q.H = H;
+    Q.W = W;
+    for (int k = 0; k < K; ++k) {
+        const int hin = k ? hs[k - 1] : H, win = k ? ws[k - 1] : W;
+        Q.lev[k] = levels[k];
+        Q.h[k] = hs[k];
+        Q.w[k] = ws[k];
+        Q.sh[k] = hs[k] > 1 ? (float)(hin - 1) / (float)(hs[k] - 1) : 0.f;
+        Q.sw[k] = ws[k] > 1 ? (float)(win - 1) / (float)(ws[k] - 1) : 0.f;
+        if (k && (hs[k] < hs[k - 1] || ws[k] < ws[k - 1])) return false;
+    }
+    // conservative bound of the region sizes of a TH x TW tile of the finest level
+    double rh = TH, rw = TW;
+    for (int k = K - 1; k > 0; --k) {
+        rh = rh * Q.sh[k] + 3;
+        rw = rw * Q.sw[k] + 3;
+        if (rh > hs[k - 1]) rh = hs[k - 1];
+        if (rw > ws[k - 1]) rw = ws[k - 1];
+        if (rh * rw > PYR_MAXR) return false;
+    }
+    Q.tiles_x = (ws[K - 1] + TW - 1) / TW;
+    Q.tiles_per_frame = Q.tiles_x * ((hs[K - 1] + TH - 1) / TH);
+    const long long nb = (long long)D * Q.tiles_per_frame;
+    if (nb > 0x3fffffff) return false;
+    Q.nblocks = (int)nb;
+    return true;
+}
+
+int resize_launch(const float *src, float *dst, int n, int hin, int win, int hout, int wout,
+                  hipStream_t st)
+{
+    const float sh = hout > 1 ? (float)(hin - 1) / (float)(hout - 1) : 0.f;
+    const float sw = wout > 1 ? (float)(win - 1) / (float)(wout - 1) : 0.f;
+    dim3 grid((wout + 63) / 64, (hout + 3) / 4, n);
+    hipLaunchKernelGGL(resize_bilinear_ac_kernel, grid, dim3(NT), 0, st, src, dst, hin, win, hout,
+                       wout, sh, sw);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+// pyramid (+ optional out-of-border count of `P`, nb_count workgroups) -> launches
+int pyramid_launch(const float *images, int D, int H, int W, float *const *levels, const int *hs,
+                   const int *ws, int K, const Params *P, int nb_count, hipStream_t st)
+{
+    if (!images || !levels || !hs || !ws || D < 0 || H < 1 || W < 1 || K < 1 ||
+        K > DVSOF_MAX_SCALES)
+        return DVSOF_EINVAL;
+    for (int k = 0; k < K; ++k)
+        if (!levels[k] || hs[k] < 1 || ws[k] < 1) return DVSOF_EINVAL;
+    static const bool no_fuse = getenv("DVSOF_LOSS_NO_FUSED_PYRAMID") != nullptr;
+    PyrParams Q;
+    if (D > 0 && !no_fuse && pyramid_plan(D, H, W, levels, hs, ws, K, images, Q)) {
+        Params dummy = {};
+        hipLaunchKernelGGL(loss_pyramid_kernel, dim3(Q.nblocks + (P ? nb_count : 0)), dim3(NT), 0, st,
+                           Q, P ? *P : dummy, P ? 1 : 0);
+        DVSOF_LAUNCH_CHECK();
+        return DVSOF_OK;
+    }
+    if (D > 65535) return DVSOF_EINVAL;
+    for (int k = 0; k < K && D > 0; ++k) {
+        const int rc = resize_launch(k ? levels[k - 1] : images, levels[k], D, k ? hs[k - 1] : H,
+                                     k ? ws[k - 1] : W, hs[k], ws[k], st);
+        if (rc) return rc;
+    }
+    if (P) {
+        hipLaunchKernelGGL(loss_count_oob_kernel, dim3(nb_count), dim3(NT), 0, st, *P);
+        DVSOF_LAUNCH_CHECK();
+    }
+    return DVSOF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -395,7 +617,8 @@ size_t dvsof_loss_workspace_bytes(const dvsof_loss_scale_t *sc, int K, int N)
     Params P;
     int nb = 0;
     if (build_params(sc, K, N, P, nb) != DVSOF_OK) return 0;
-    return (size_t)nb * NPART * sizeof(float);
+    size_t g, c;
+    return ws_layout(nb, K, N, g, c);
 }
 
 int dvsof_resize_bilinear_ac(const float *src, float *dst, int n, int hin, int win, int hout,
@@ -404,14 +627,26 @@ int dvsof_resize_bilinear_ac(const float *src, float *dst, int n, int hin, int w
     if (!src || !dst || n < 0 || hin < 1 || win < 1 || hout < 1 || wout < 1) return DVSOF_EINVAL;
     if (n == 0) return DVSOF_OK;
     if (n > 65535) return DVSOF_EINVAL;
-    const float sh = hout > 1 ? (float)(hin - 1) / (float)(hout - 1) : 0.f;
-    const float sw = wout > 1 ? (float)(win - 1) / (float)(wout - 1) : 0.f;
-    dim3 grid((wout + 63) / 64, (hout + 3) / 4, n);
-    hipLaunchKernelGGL(resize_bilinear_ac_kernel, grid, dim3(NT), 0, as_stream(stream), src, dst,
-                       hin, win, hout, wout, sh, sw);
+    return resize_launch(src, dst, n, hin, win, hout, wout, as_stream(stream));
+}
+
+int dvsof_loss_pyramid(const float *images, int D, int H, int W, float *const *levels,
+                       const int *hs, const int *ws, int K, void *stream)
+{
+    return pyramid_launch(images, D, H, W, levels, hs, ws, K, nullptr, 0, as_stream(stream));
+}
+
+namespace {
+int finalize_launch(const Params &P, float *terms, float *loss_out, const float *w,
+                    float loss_scale, int write_oob, hipStream_t st)
+{
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(P.K * P.N), dim3(NT), 0, st, P, P.group, P.counter,
+                       terms, loss_out, w ? w[0] : 0.f, w ? w[1] : 0.f, w ? w[2] : 0.f, loss_scale,
+                       write_oob);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
+}  // namespace
 
 int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
                    const int32_t *stop, float *terms, int32_t *oob, void *ws, size_t ws_bytes,
@@ -422,18 +657,16 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     const int rc = build_params(sc, K, N, P, nb);
     if (rc) return rc;
     if (!start || !stop || !terms || !oob || !ws) return DVSOF_EINVAL;
-    if (ws_bytes < (size_t)nb * NPART * sizeof(float)) return DVSOF_ENOSPACE;
+    size_t g, c;
+    if (ws_bytes < ws_layout(nb, K, N, g, c)) return DVSOF_ENOSPACE;
     P.start = start;
     P.stop = stop;
-    P.partials = (float *)ws;
+    bind_ws(P, ws, nb);
     P.oob = oob;
     P.seeds_dev = nullptr;
     hipLaunchKernelGGL((loss_main_kernel<true, false>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
     DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(NT), 0, as_stream(stream), P, terms,
-                       (float *)nullptr, 0.f, 0.f, 0.f, 1.f, 1);
-    DVSOF_LAUNCH_CHECK();
-    return DVSOF_OK;
+    return finalize_launch(P, terms, nullptr, nullptr, 1.f, 1, as_stream(stream));
 }
 
 int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
@@ -449,6 +682,8 @@ int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     P.start = start;
     P.stop = stop;
     P.partials = nullptr;
+    P.group = nullptr;
+    P.counter = nullptr;
     P.oob = const_cast<int32_t *>(oob);
     P.seeds_dev = seeds;
     hipLaunchKernelGGL((loss_main_kernel<false, true>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
@@ -456,9 +691,13 @@ int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     return DVSOF_OK;
 }
 
-int dvsof_loss_fused(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
-                     const int32_t *stop, const float *w, float loss_scale, float *terms,
-                     float *loss_out, int32_t *oob, void *ws, size_t ws_bytes, void *stream)
+namespace {
+// images != NULL: the frame pyramid is built into sc[k].frames first (same
+// launch as the out-of-border count)
+int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_t *sc, int K, int N,
+               const int32_t *start, const int32_t *stop, const float *w, float loss_scale,
+               float *terms, float *loss_out, int32_t *oob, void *ws, size_t ws_bytes,
+               hipStream_t st)
 {
     Params P;
     int nb = 0;
@@ -467,22 +706,51 @@ int dvsof_loss_fused(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *
     if (!start || !stop || !w || !terms || !loss_out || !oob || !ws) return DVSOF_EINVAL;
     for (int k = 0; k < K; ++k)
         if (!sc[k].grad_flow) return DVSOF_EINVAL;
-    if (ws_bytes < (size_t)nb * NPART * sizeof(float)) return DVSOF_ENOSPACE;
+    size_t g, c;
+    if (ws_bytes < ws_layout(nb, K, N, g, c)) return DVSOF_ENOSPACE;
     P.start = start;
     P.stop = stop;
-    P.partials = (float *)ws;
+    bind_ws(P, ws, nb);
     P.oob = oob;
     P.seeds_dev = nullptr;
     for (int i = 0; i < 3; ++i) P.seeds_host[i] = w[i] / (float)K * loss_scale;
-    DVSOF_HIP_TRY(hipMemsetAsync(oob, 0, sizeof(int32_t) * (size_t)K * N, as_stream(stream)));
-    hipLaunchKernelGGL(loss_count_oob_kernel, dim3(nb), dim3(NT), 0, as_stream(stream), P);
+    DVSOF_HIP_TRY(hipMemsetAsync(oob, 0, sizeof(int32_t) * (size_t)K * N, st));
+    if (images) {
+        float *levels[DVSOF_MAX_SCALES];
+        int hs[DVSOF_MAX_SCALES], wss[DVSOF_MAX_SCALES];
+        for (int k = 0; k < K; ++k) {
+            levels[k] = const_cast<float *>(sc[k].frames);
+            hs[k] = sc[k].h;
+            wss[k] = sc[k].w;
+        }
+        const int prc = pyramid_launch(images, D, H, W, levels, hs, wss, K, &P, nb, st);
+        if (prc) return prc;
+    } else {
+        hipLaunchKernelGGL(loss_count_oob_kernel, dim3(nb), dim3(NT), 0, st, P);
+        DVSOF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((loss_main_kernel<true, true>), dim3(nb), dim3(NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((loss_main_kernel<true, true>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
-    DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(NT), 0, as_stream(stream), P, terms,
-                       loss_out, w[0], w[1], w[2], loss_scale, 0);
-    DVSOF_LAUNCH_CHECK();
-    return DVSOF_OK;
+    return finalize_launch(P, terms, loss_out, w, loss_scale, 0, st);
+}
+}  // namespace
+
+int dvsof_loss_fused(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
+                     const int32_t *stop, const float *w, float loss_scale, float *terms,
+                     float *loss_out, int32_t *oob, void *ws, size_t ws_bytes, void *stream)
+{
+    return fused_impl(nullptr, 0, 0, 0, sc, K, N, start, stop, w, loss_scale, terms, loss_out, oob, ws,
+                      ws_bytes, as_stream(stream));
+}
+
+int dvsof_loss_fused_pyramid(const float *images, int D, int H, int W,
+                             const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
+                             const int32_t *stop, const float *w, float loss_scale, float *terms,
+                             float *loss_out, int32_t *oob, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!images || D < 1 || H < 1 || W < 1) return DVSOF_EINVAL;
+    return fused_impl(images, D, H, W, sc, K, N, start, stop, w, loss_scale, terms, loss_out, oob, ws,
+                      ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

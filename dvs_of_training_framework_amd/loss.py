@@ -103,10 +103,12 @@ class _LossTerms(torch.autograd.Function):
 
 class _FusedLoss(torch.autograd.Function):
     """loss = sum_t w_t * mean_k term[t,k] * scale with the flow gradients
-    produced in the same sweep (dvsof_loss_fused)."""
+    produced in the same sweep (dvsof_loss_fused).  ``images`` not None: the
+    frame pyramid is built into ``frames`` by the same call
+    (dvsof_loss_fused_pyramid)."""
 
     @staticmethod
-    def forward(ctx, frames, start, stop, weights, scale, *flows):
+    def forward(ctx, frames, images, start, stop, weights, scale, *flows):
         K, N = len(flows), flows[0].shape[0]
         dev = flows[0].device
         flows = tuple(f.detach().contiguous().float() for f in flows)
@@ -117,17 +119,25 @@ class _FusedLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         oob = torch.empty(K * N, dtype=torch.int32, device=dev)
         w = (ctypes.c_float * 3)(*[float(x) for x in weights])
-        _lib.check(_lib.lib().dvsof_loss_fused(
-            arr, K, N, start.data_ptr(), stop.data_ptr(), w, float(scale),
-            terms.data_ptr(), loss.data_ptr(), oob.data_ptr(),
-            ws.data_ptr(), nbytes, _lib.stream()), 'dvsof_loss_fused')
+        if images is None:
+            _lib.check(_lib.lib().dvsof_loss_fused(
+                arr, K, N, start.data_ptr(), stop.data_ptr(), w, float(scale),
+                terms.data_ptr(), loss.data_ptr(), oob.data_ptr(),
+                ws.data_ptr(), nbytes, _lib.stream()), 'dvsof_loss_fused')
+        else:
+            D, H, W = images.shape
+            _lib.check(_lib.lib().dvsof_loss_fused_pyramid(
+                images.data_ptr(), D, H, W, arr, K, N, start.data_ptr(),
+                stop.data_ptr(), w, float(scale), terms.data_ptr(),
+                loss.data_ptr(), oob.data_ptr(), ws.data_ptr(), nbytes,
+                _lib.stream()), 'dvsof_loss_fused_pyramid')
         ctx.grads = grads
         ctx.mark_non_differentiable(terms)
         return loss, terms
 
     @staticmethod
     def backward(ctx, g_loss, _g_terms):
-        return (None,) * 5 + tuple(g * g_loss for g in ctx.grads)
+        return (None,) * 6 + tuple(g * g_loss for g in ctx.grads)
 
 
 class Loss:
@@ -179,11 +189,8 @@ class Losses:
         self.losses = [Loss(s, batch_size, device, timers)
                        for s in self.shapes]
 
-    def _pyramid(self, flows, images):
-        """CASCADE: level k resamples level k-1 (utils/loss.py:207-210)."""
+    def _check_flows(self, flows):
         assert len(flows) == len(self.shapes)
-        frames, cur = [], images.detach()
-        cur = cur.reshape(cur.shape[0], cur.shape[-2], cur.shape[-1])
         for flow, shape in zip(flows, self.shapes):
             assert tuple(flow.shape[-2:]) == shape, \
                 f'flow of size {tuple(flow.shape[-2:])} given to the ' \
@@ -192,9 +199,28 @@ class Losses:
                 'Flow should contain 2 channels (dx and dy)'
             assert flow.shape[0] <= self.N, 'This object should be used ' \
                 f'for batch of at most {self.N} samples'
-            cur = interpolate(cur, shape)
-            frames.append(cur)
-        return tuple(frames)
+
+    def _level_buffers(self, images):
+        img = images.detach().contiguous().float()
+        img = img.reshape(img.shape[0], img.shape[-2], img.shape[-1])
+        frames = tuple(torch.empty(img.shape[0], h, w, dtype=torch.float32,
+                                   device=img.device) for h, w in self.shapes)
+        return img, frames
+
+    def _pyramid(self, flows, images):
+        """CASCADE: level k resamples level k-1 (utils/loss.py:207-210), all
+        levels by one call (dvsof_loss_pyramid)."""
+        self._check_flows(flows)
+        img, frames = self._level_buffers(images)
+        K = len(frames)
+        ptrs = (ctypes.c_void_p * K)(*[f.data_ptr() for f in frames])
+        hs = (ctypes.c_int * K)(*[s[0] for s in self.shapes])
+        ws = (ctypes.c_int * K)(*[s[1] for s in self.shapes])
+        D, H, W = img.shape
+        _lib.check(_lib.lib().dvsof_loss_pyramid(
+            img.data_ptr(), D, H, W, ptrs, hs, ws, K, _lib.stream()),
+            'dvsof_loss_pyramid')
+        return frames
 
     def _prepare(self, flows, flow_ts, flow_sample_idx, images, timestamps,
                  sample_idx, frame_indices):
@@ -218,11 +244,17 @@ class Losses:
               sample_idx, weights=(0.5, 1, 1), loss_scale=1.0,
               frame_indices=None):
         """-> (loss, terms[3,K]); same value as combined_loss
-        (reference utils/training.py:12-24) times loss_scale."""
-        frames, start, stop = self._prepare(flows, flow_ts, flow_sample_idx,
-                                            images, timestamps, sample_idx,
-                                            frame_indices)
-        return _FusedLoss.apply(frames, start, stop, tuple(weights),
+        (reference utils/training.py:12-24) times loss_scale.  Pyramid,
+        out-of-border count, terms and flow gradients: 4 launches."""
+        _lib.require_cuda(images, *flows)
+        if frame_indices is None:
+            frame_indices = resolve_frames(flow_ts, flow_sample_idx,
+                                           timestamps, sample_idx)
+        start, stop = frame_indices
+        assert start.numel() == flows[0].shape[0]
+        self._check_flows(flows)
+        img, frames = self._level_buffers(images)
+        return _FusedLoss.apply(frames, img, start, stop, tuple(weights),
                                 loss_scale, *flows)
 
 

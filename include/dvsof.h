@@ -115,6 +115,17 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
 int dvsof_resize_bilinear_ac(const float *src, float *dst, int n, int hin,
                              int win, int hout, int wout, void *stream);
 
+/*
+ * The whole CASCADED pyramid of utils/loss.py:207-210 (level 0 resamples
+ * images [D,H,W] to (hs[0],ws[0]); level k resamples level k-1) into
+ * levels[k] = float[D*hs[k]*ws[k]].  One launch when the level sizes are
+ * non-decreasing (the coarse -> fine order Losses uses), otherwise one resize
+ * launch per level; bitwise the same values either way.
+ */
+int dvsof_loss_pyramid(const float *images, int D, int H, int W,
+                       float *const *levels, const int *hs, const int *ws,
+                       int num_levels, void *stream);
+
 typedef struct {
     const float *frames; /* [D,h,w] all frames of the batch at this scale */
     const float *flow;   /* [N,2,h,w] predicted flow, pixels of this scale */
@@ -164,6 +175,21 @@ int dvsof_loss_fused(const dvsof_loss_scale_t *host_scales, int num_scales,
                      const float *host_weights /*[3]*/, float loss_scale,
                      float *terms, float *loss_out, int32_t *oob_count,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * dvsof_loss_fused that first builds the frame pyramid from images [D,H,W]
+ * INTO host_scales[k].frames (as dvsof_loss_pyramid does), sharing a launch
+ * with the out-of-border count: Losses.__call__'s interpolate cascade
+ * (utils/loss.py:207-210) + terms + gradient in 4 launches.
+ */
+int dvsof_loss_fused_pyramid(const float *images, int D, int H, int W,
+                             const dvsof_loss_scale_t *host_scales,
+                             int num_scales, int N, const int32_t *start_idx,
+                             const int32_t *stop_idx,
+                             const float *host_weights /*[3]*/,
+                             float loss_scale, float *terms, float *loss_out,
+                             int32_t *oob_count, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 
 /* ------------------------------------------------------------------ *

@@ -165,3 +165,31 @@ def test_baseline_size_properties():
                                c['images'], c['timestamps'], c['sample_idx'],
                                with_grad=False)
     np.testing.assert_allclose(ta[:, :2], o_terms, rtol=TERM_RTOL)
+
+
+@pytest.mark.parametrize('src,shapes', [
+    ((256, 256), [(32, 32), (64, 64), (128, 128), (256, 256)]),     # config 2
+    ((260, 346), [(33, 44), (65, 87), (130, 173), (260, 346)]),     # odd sizes
+    ((480, 640), [(60, 80), (120, 160), (240, 320), (480, 640)]),   # config 4
+    ((64, 64), [(64, 64)]),                                         # one level
+    ((96, 80), [(12, 10), (12, 10), (48, 40)]),                     # equal levels
+    ((64, 64), [(32, 32), (16, 16)]),                               # shrinking: per-level path
+])
+def test_pyramid_one_launch_is_bitwise_the_cascade(src, shapes):
+    """dvsof_loss_pyramid == K dependent dvsof_resize_bilinear_ac calls
+    (utils/loss.py:207-210), bit for bit, and == torch's interpolate within
+    float rounding."""
+    from dvs_of_training_framework_amd.loss import Losses, interpolate
+    D = 6
+    g = torch.Generator().manual_seed(5)
+    img = (torch.rand(D, 1, *src, generator=g) * 255).cuda()
+    ev = Losses(shapes, D // 2, 'cuda')
+    flows = [torch.zeros(D // 2, 2, h, w, device='cuda') for h, w in shapes]
+    levels = ev._pyramid(flows, img)
+    cur, ref = img[:, 0], img
+    for lev, shape in zip(levels, shapes):
+        cur = interpolate(cur, shape)
+        assert torch.equal(lev, cur), shape
+        ref = torch.nn.functional.interpolate(ref, size=shape, mode='bilinear',
+                                              align_corners=True)
+        assert float((lev - ref[:, 0]).abs().max()) <= 1e-3
