@@ -404,24 +404,35 @@ __global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, doubl
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const double v = block_sum(a[i], sh, tid);
-            if (tid == 0) group[(size_t)blockIdx.x * NGROUP + i] = v;
+            // agent-scope (write-through) store: visible to the last workgroup on
+            // any XCD without a full L2 write-back (__threadfence() costs ~20 us
+            // here: the L2 is full of the step's dirty activations)
+            if (tid == 0)
+                __hip_atomic_store(&group[(size_t)blockIdx.x * NGROUP + i], v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             if (i == 6 && tid == 0 && write_oob) P.oob[k * P.N + n] = (int)v;
         }
     }
-    __threadfence();
-    if (tid == 0) s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores above have been acknowledged
+        s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                 (int)gridDim.x - 1;
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     // items (k, i): i < 5 global sums of photo + four smoothness directions,
     // i == 5: border term = sum_n bs_n / (2 c_n N)  (utils/loss.py:101,113)
     for (int kk = 0; kk < P.K; ++kk) {
         double a[6] = {0, 0, 0, 0, 0, 0};
         for (int nn = tid; nn < P.N; nn += NT) {
-            const volatile double *g = group + ((size_t)kk * P.N + nn) * NGROUP;
+            const double *g = group + ((size_t)kk * P.N + nn) * NGROUP;
+            double r[7];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) a[i] += g[i];
-            const double bs = g[5], c = g[6];
+            for (int i = 0; i < 7; ++i)
+                r[i] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[i] += r[i];
+            const double bs = r[5], c = r[6];
             if (c > 0) a[5] += bs / (2.0 * c * (double)P.N);
         }
 #pragma unroll
