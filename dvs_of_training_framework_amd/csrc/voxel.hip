@@ -335,7 +335,8 @@ int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t, con
     P.x = x; P.y = y; P.pol = pol; P.sample = sample; P.t = t; P.t0 = t0; P.t1 = t1;
     P.n = n; P.B = B; P.C = C; P.H = H; P.W = W;
     P.out = out; P.bin0 = bin0; P.lin0 = lin0;
-    DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, ((size_t)P.ntile + 1) * 4, st));
+    // cursor[ntile] + ovf_count, rounded up to 64 B (one fill kernel, no tail)
+    DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, (((size_t)P.ntile + 1) * 4 + 63) / 64 * 64, st));
     const int nb = (int)((n + (int64_t)NT * EPT - 1) / ((int64_t)NT * EPT));
     hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb), dim3(NT), (size_t)P.ntile * 8, st, P);
     DVSOF_LAUNCH_CHECK();
@@ -381,7 +382,8 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
     P.t = t; P.t0 = t0; P.t1 = t1;
     P.n = n; P.B = B; P.C = C; P.H = H; P.W = W;
     P.out = out; P.bin0 = bin0; P.lin0 = lin0;
-    DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, ((size_t)P.ntile + 1) * 4, st));
+    // cursor[ntile] + ovf_count, rounded up to 64 B (one fill kernel, no tail)
+    DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, (((size_t)P.ntile + 1) * 4 + 63) / 64 * 64, st));
     const int nb = (int)((n + (int64_t)NT * EPT - 1) / ((int64_t)NT * EPT));
     hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb), dim3(NT), (size_t)P.ntile * 8, st, P);
     DVSOF_LAUNCH_CHECK();

@@ -133,11 +133,15 @@ class _FusedLoss(torch.autograd.Function):
                 _lib.stream()), 'dvsof_loss_fused_pyramid')
         ctx.grads = grads
         ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)
         return loss, terms
 
     @staticmethod
     def backward(ctx, g_loss, _g_terms):
-        return (None,) * 6 + tuple(g * g_loss for g in ctx.grads)
+        if g_loss is None:
+            return (None,) * (6 + len(ctx.grads))
+        # one multi-tensor launch for all scales
+        return (None,) * 6 + tuple(torch._foreach_mul(list(ctx.grads), g_loss))
 
 
 class Loss:

@@ -63,6 +63,7 @@ class Model(nn.Module):
         # device sync per call); the train loop turns it off after step one.
         self.strict = True
         self.last_frame_indices = None
+        self._layout_cache, self._fast = {}, None
         self.to(device)
 
     # ---- host/device bookkeeping -------------------------------------
@@ -75,11 +76,24 @@ class Model(nn.Module):
         local, sizes = None, None
         if D == batch * (2 + self.prefix_length + self.suffix_length) and \
                 not self.strict:
-            T = D // batch                     # uniform, sample-major layout
-            first = torch.arange(batch, device=dev) * T
-            start = first + self.prefix_length
-            t0, t1 = timestamps[first], timestamps[first + T - 1]
-            return start, start + 1, t0, t1
+            # uniform, sample-major layout: every index vector is a constant
+            # of (D, batch): built once, then ONE gather per step
+            key = (D, batch, self.prefix_length, str(dev))
+            c = self._layout_cache.get(key)
+            if c is None:
+                T = D // batch
+                first = torch.arange(batch, device=dev) * T
+                start = first + self.prefix_length
+                c = dict(start=start, stop=start + 1,
+                         gather=torch.cat([first, first + T - 1, start,
+                                           start + 1]),
+                         start32=start.to(torch.int32),
+                         stop32=(start + 1).to(torch.int32))
+                self._layout_cache = {key: c}
+            g = timestamps[c['gather']]
+            self._fast = (c, g)
+            return c['start'], c['stop'], g[:batch], g[batch:2 * batch]
+        self._fast = None
         local, sizes = get_local_idx(sample_idx)
         if self.strict and not self.dynamic_sample_length:
             assert bool((sizes == (2 + self.prefix_length +
@@ -132,9 +146,14 @@ class Model(nn.Module):
             flows = tuple(f[:, :, :h // 2 ** i, :w // 2 ** i]
                           for f, i in zip(flows, (3, 2, 1, 0)))
         with torch.no_grad():
-            flow_ts = torch.stack([timestamps[start], timestamps[stop]], 1)
+            if self._fast is not None:
+                c, g = self._fast
+                flow_ts = g[2 * batch:].view(2, batch).t()
+                self.last_frame_indices = (c['start32'], c['stop32'])
+            else:
+                flow_ts = torch.stack([timestamps[start], timestamps[stop]], 1)
+                self.last_frame_indices = (start.to(torch.int32),
+                                           stop.to(torch.int32))
             flow_sample_idx = sample_idx[start]
-        self.last_frame_indices = (start.to(torch.int32),
-                                   stop.to(torch.int32))
         add_info = (tuple(), ) if intermediate else tuple()
         return (tuple(flows), flow_ts, flow_sample_idx) + add_info
