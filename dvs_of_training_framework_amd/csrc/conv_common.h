@@ -58,7 +58,7 @@ struct GConvParams {
     int bwd_act;        // activation kind for actsrc
     int ph_exact;       // phased stride-2 dgrad: phase (py,px) only has (1+py) x (1+px) non-zero
                         // taps; a kernel MAY skip the others (they multiply zero weights)
-    int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step
+    int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step, 4 = loads from one L2-resident KiB
 };
 
 // Weight-gradient problem (wgrad.hip)

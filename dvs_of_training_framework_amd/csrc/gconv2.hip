@@ -55,7 +55,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     constexpr int PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
     // a stage holds KSUB consecutive 16-channel slices of one tap (K depth
     // 16*KSUB per barrier: halves the per-slice sync cost at 1-2 waves/SIMD)
-    static_assert(KSPLIT == 1 || KSUB == 2, "wave groups split the two sub-slices");
+    static_assert(KSUB % KSPLIT == 0, "wave groups split the sub-slices of a stage");
     constexpr int NT = CONV_NT * KSPLIT;
     constexpr int KPW = KSUB / KSPLIT;            // sub-slices a wave loads and multiplies
     constexpr int LPW = (PA + PB) / 4 * KPW;      // loads per wave per stage
@@ -300,7 +300,9 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                     const int p = wave + 4 * i;     // SGPR
                     __attribute__((address_space(3))) void *dst =
                         (__attribute__((address_space(3))) void *)(st + p * 1024);
-                    if (p < PA)
+                    if (P.dbg & 4) {   // timing probe: every load hits the same few KiB (L2-resident)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, slot_kq4[i] + (lane >> 2) * 64, 0, 0, 0);
+                    } else if (p < PA)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, dst, 16, voff[i], a_soff, 0, 0);
                     else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, voff[i], b_soff, 0, 0);
@@ -465,7 +467,17 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
         const long long blocks = ((P.M + bm - 1) / bm) * ((P.N + bn - 1) / bn) * P.nph;
         if (blocks > 2 * 256) k32 = false;
     }
-    const int ksub = k32 ? 2 : 1;
+    int ksub = k32 ? 2 : 1;
+    // one workgroup per CU (8-wave form): K depth 64 per barrier -- both waves of
+    // a SIMD reach the barrier together, so the sync/issue bubble is paid per stage
+    bool k64 = false;
+    if (tile == 3 && k32 && !getenv("DVSOF_GCONV_NO_K64")) {
+        const long long blocks = ((P.M + 63) / 64) * ((P.N + 63) / 64) * P.nph;
+        k64 = blocks <= 256;
+        for (int s = 0; s < P.nsrc; ++s)
+            if (P.src[s].flat || (P.src[s].C % (4 * BK))) k64 = false;
+        if (k64) ksub = 4;
+    }
     int nflat = 0, nvec = 0;
     for (int s = 0; s < P.nsrc; ++s) {
         if (P.src[s].flat) nflat += (taps * P.src[s].C + BK - 1) / BK;
@@ -481,8 +493,12 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
         // <= 1 workgroup per CU: 8-wave form (two waves per SIMD from one workgroup)
         static const bool no8 = getenv("DVSOF_GCONV_NO_KSPLIT") != nullptr;
         const long long blocks = ((P.M + 63) / 64) * ((P.N + 63) / 64) * P.nph;
+        // ring depth 2 (64 KiB): a deeper ring is no faster stand-alone and its LDS
+        // footprint keeps the second stream's workgroups off the CU
+        if (k64 && !no8) return launch2<2, 2, 1, 1, 4, 2, 2>(P, nflat, nvec, st);
+        if (k64) { /* 4-wave fallback keeps K32 counting */ return DVSOF_EINVAL; }
         if (k32 && !no8 && nflat == 0 && blocks <= 256)
-            { static const int ns8 = getenv("DVSOF_NS") ? atoi(getenv("DVSOF_NS")) : 4; if (ns8 == 8) return launch2<2, 2, 1, 1, 2, 8, 2>(P, nflat, nvec, st); if (ns8 == 6) return launch2<2, 2, 1, 1, 2, 6, 2>(P, nflat, nvec, st); return launch2<2, 2, 1, 1, 2, 4, 2>(P, nflat, nvec, st); }
+            return launch2<2, 2, 1, 1, 2, 4, 2>(P, nflat, nvec, st);
         return k32 ? launch2<2, 2, 1, 1, 2, 4>(P, nflat, nvec, st)
                    : launch2<2, 2, 1, 1, 1, 4>(P, nflat, nvec, st);  // 64 x 64
     }
