@@ -50,6 +50,11 @@ _SIGNATURES = {
     'dvsof_loss_fused': (_i, [ctypes.POINTER(LossScale), _i, _i, _vp, _vp,
                               ctypes.POINTER(_f), _f, _vp, _vp, _vp, _vp,
                               _sz, _vp]),
+    'dvsof_augment_lut': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'dvsof_augment_frames': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i,
+                                  _i, _vp, _vp]),
+    'dvsof_augment_events': (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i,
+                                  _i, _vp, _vp, _vp]),
     'dvsof_loss_pyramid': (_i, [_vp, _i, _i, _i, ctypes.POINTER(_vp),
                                 ctypes.POINTER(_i), ctypes.POINTER(_i), _i,
                                 _vp]),

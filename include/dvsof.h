@@ -104,6 +104,39 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
                            size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ *
+ * Data augmentation on the device: horizontal
+ * flip -> nearest-neighbour LUT rotation about the frame centre -> crop, the
+ * order of utils/dataset.py:753-769.  Per-sample parameters are device
+ * arrays: flip u8[B]; cos_sin f64[B][2] (cos, sin of the angle, computed on
+ * the host in float64 as utils/data.py:181-186 does); box i32[B][4] =
+ * (y0, x0, h, w) with one (h, w) for the whole batch.
+ * ------------------------------------------------------------------ */
+
+/* lut[b][source pixel] = rotated pixel that reads it (smallest index when
+ * several do; >= H*W: none).  Replaces the (src, dst) index lists
+ * RandomRotation hands to the native transformation.map, utils/data.py:199-215. */
+int dvsof_augment_lut(const double *cos_sin, int B, int H, int W, int32_t *lut,
+                      void *stream);
+
+/* dst f32[D,h,w] = crop(rotate(flip(src[D,H,W]))); src is u8 or f32;
+ * frame_sample i32[D] = sample of every frame.  utils/dataset.py:755-757,
+ * utils/data.py:203-206 (rimages), utils/data.py:45-75 (crop). */
+int dvsof_augment_frames(const void *src, int src_is_u8, int D, int H, int W,
+                         const int32_t *frame_sample, const uint8_t *flip,
+                         const double *cos_sin, const int32_t *box, int h,
+                         int w, float *dst, void *stream);
+
+/* Event coordinates through the same flip / rotation / crop
+ * (utils/dataset.py:758, utils/data.py:208-213, utils/data.py:24-42).  lut
+ * may be NULL (no rotation).  Removed events get x_out = y_out = -1 instead of
+ * being compacted away (the voxeliser skips them). */
+int dvsof_augment_events(const int64_t *x, const int64_t *y,
+                         const int64_t *sample_index, int64_t n_events,
+                         const uint8_t *flip, const int32_t *lut,
+                         const int32_t *box, int B, int H, int W,
+                         int64_t *x_out, int64_t *y_out, void *stream);
+
+/* ------------------------------------------------------------------ *
  * Multi-scale warp / Charbonnier / smoothness / out-of-border loss
  * ------------------------------------------------------------------ */
 

@@ -168,3 +168,53 @@ def voxelize(events, t0, t1, B, C, H, W):
                        _p(s, c_i64), n, _p(t0, c_f), _p(t1, c_f), B, C, H, W,
                        _p(out, c_f), _p(bin0, c_i32), _p(lin0, c_i64))
     return out, bin0[:n], lin0[:n]
+
+
+# ---------------------------------------------------------------------------
+# Data augmentation: horizontal flip, LUT rotation,
+# crop -- restated from /root/reference/utils/dataset.py:753-769 (order: flip,
+# rotate, crop), utils/data.py:155-220 (RandomRotation) and :24-42 (EventCrop).
+# The event side of the rotation goes through the reference's native
+# ``transformation.map`` whose source is absent: PARITY UNPINNED where several
+# rotated pixels read the same source pixel (events there go to the SMALLEST
+# such pixel index -- this file's rule); bijective cases (multiples of 90
+# degrees) are pinned by tests/dataset/test_dataset.py:76-170.
+# ---------------------------------------------------------------------------
+def rotation_sources(angle, H, W):
+    """-> src_y, src_x int64[H,W] (source pixel of every rotated pixel) and the
+    validity mask (utils/data.py:166-199)."""
+    x, y = np.meshgrid(range(W), range(H))
+    x, y = x.ravel().astype(float) - W / 2, y.ravel().astype(float) - H / 2
+    rad = angle * np.pi / 180
+    c, s = np.cos(rad), np.sin(rad)
+    x1 = np.rint(c * x + (-s) * y + W / 2).astype(np.int64)
+    y1 = np.rint(s * x + c * y + H / 2).astype(np.int64)
+    ok = (x1 >= 0) & (x1 < W) & (y1 >= 0) & (y1 < H)
+    return y1.reshape(H, W), x1.reshape(H, W), ok.reshape(H, W)
+
+
+def augment_sample(images, x, y, is_flip, angle, box):
+    """images [n,H,W]; x, y int arrays of the sample's events;
+    box = (y0, x0, h, w).  -> images [n,h,w] float32, new x, new y with -1 for
+    events the rotation or the crop drops (the reference removes them)."""
+    images = np.asarray(images)
+    n, H, W = images.shape
+    x, y = np.asarray(x, np.int64).copy(), np.asarray(y, np.int64).copy()
+    if is_flip:                                   # utils/dataset.py:755-758
+        images = images[..., ::-1]
+        x = W - x - 1
+    sy, sx, ok = rotation_sources(angle, H, W)    # utils/data.py:181-205
+    rimg = np.zeros_like(images)
+    rimg[:, ok] = images[:, sy[ok], sx[ok]]
+    lut = np.full(H * W, -1, np.int64)            # source pixel -> rotated pixel
+    dst = np.flatnonzero(ok.ravel())
+    src = (sy * W + sx).ravel()[dst]
+    # smallest rotated index wins: write in decreasing order
+    lut[src[::-1]] = dst[::-1]
+    o = lut[y * W + x]
+    oy, ox = o // W, o % W
+    y0, x0, h, w = (int(v) for v in box)          # utils/data.py:24-42
+    keep = (o >= 0) & (ox >= x0) & (ox < x0 + w) & (oy >= y0) & (oy < y0 + h)
+    nx = np.where(keep, ox - x0, -1)
+    ny = np.where(keep, oy - y0, -1)
+    return rimg[:, y0:y0 + h, x0:x0 + w].astype(np.float32), nx, ny

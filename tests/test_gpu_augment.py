@@ -1,0 +1,124 @@
+"""Device augmentation (flip / LUT rotation / crop) against the numpy
+restatement of the reference (oracle.cpu_oracle.augment_sample) -- bit-exact --
+and the reference's own property tests (tests/dataset/test_dataset.py:76-218)
+restated on its HDF5 fixtures (tests/golden/fixtures.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_oracle as orc
+
+pytestmark = pytest.mark.gpu
+H, W = 260, 346
+
+
+def fixture_batch(fixtures, ids):
+    """wire-format batch from fixture elements `ids` (two frames each)."""
+    xs, ys, ss, frames, sidx = [], [], [], [], []
+    for b, i in enumerate(ids):
+        ev = fixtures[f'events_{i}']
+        xs.append(ev[:, 0].astype(np.int64))
+        ys.append(ev[:, 1].astype(np.int64))
+        ss.append(np.full(len(ev), b, np.int64))
+        frames += [fixtures['frames'][i], fixtures['frames'][i + 1]]
+        sidx += [b, b]
+    x, y, s = map(np.concatenate, (xs, ys, ss))
+    return {'events': {'x': torch.from_numpy(x), 'y': torch.from_numpy(y),
+                       'sample_index': torch.from_numpy(s)},
+            'images': torch.from_numpy(np.stack(frames))[:, None],
+            'sample_idx': torch.tensor(sidx), 'size': len(ids),
+            'augmentation_params': {}}
+
+
+def run(fixtures, ids, is_flip, angle, box):
+    from dvs_of_training_framework_amd.augment import augment_batch
+    out = augment_batch(fixture_batch(fixtures, ids), is_flip, angle, box)
+    return (out['images'][:, 0].cpu().numpy(), out['events']['x'].cpu().numpy(),
+            out['events']['y'].cpu().numpy(), out)
+
+
+@pytest.mark.parametrize('case', [
+    dict(is_flip=[False, True, True], angle=[0, 0, 0], box=[[0, 0, H, W]] * 3),
+    dict(is_flip=[False, False, True], angle=[90, -90, 180], box=[[0, 0, H, W]] * 3),
+    dict(is_flip=[True, False, True], angle=[37.5, -20.25, 3.0],
+         box=[[1, 2, 100, 150], [160, 196, 100, 150], [50, 60, 100, 150]]),
+    dict(is_flip=[False, True, False], angle=[0, 12.5, -29.9],
+         box=[[4, 90, 256, 256], [0, 0, 256, 256], [3, 17, 256, 256]]),
+])
+def test_matches_the_numpy_restatement_bit_for_bit(fixtures, case):
+    ids = [1, 4, 7]
+    img, x, y, out = run(fixtures, ids, case['is_flip'], case['angle'], case['box'])
+    b = fixture_batch(fixtures, ids)
+    s = b['events']['sample_index'].numpy()
+    for k, i in enumerate(ids):
+        m = s == k
+        ri, rx, ry = orc.augment_sample(
+            b['images'][2 * k:2 * k + 2, 0].numpy(), b['events']['x'].numpy()[m],
+            b['events']['y'].numpy()[m], case['is_flip'][k], case['angle'][k],
+            case['box'][k])
+        assert np.array_equal(img[2 * k:2 * k + 2], ri)
+        assert np.array_equal(x[m], rx) and np.array_equal(y[m], ry)
+    assert out['augmentation_params']['angle'].tolist() == list(map(float, case['angle']))
+
+
+def test_reference_flip_property(fixtures):
+    """tests/dataset/test_dataset.py:76-116: a pixel under an event keeps its
+    value when both are flipped."""
+    full = [[0, 0, H, W]]
+    a, ax, ay, _ = run(fixtures, [1], [True], [0], full)
+    b, bx, by, _ = run(fixtures, [1], [False], [0], full)
+    assert (a != b).any() and a.shape == b.shape
+    for i in range(a.shape[0]):
+        assert (a[i][ay, ax] == b[i][by, bx]).all()
+
+
+def test_reference_rotation_property(fixtures):
+    """tests/dataset/test_dataset.py:119-170: 90 degrees is the index map
+    x0 = -(y - H/2) + W/2, y0 = (x - W/2) + H/2 on images and events."""
+    full = [[0, 0, H, W]]
+    r, rx, ry, _ = run(fixtures, [1], [False], [90], full)
+    o, _, _, _ = run(fixtures, [1], [False], [0], full)
+    keep = rx >= 0
+    assert keep.any() and (ry[keep] >= 0).all()
+    x0 = -(ry[keep] - H // 2) + W // 2
+    y0 = (rx[keep] - W // 2) + H // 2
+    assert (y0 < H).all() and (y0 >= 0).all() and (x0 < W).all() and (x0 >= 0).all()
+    assert (o != r).any()
+    for i in range(o.shape[0]):
+        assert (o[i][y0, x0] == r[i][ry[keep], rx[keep]]).all()
+
+
+def test_reference_crop_property(fixtures):
+    """tests/dataset/test_dataset.py:173-218."""
+    box = [1, 2, 100, 150]
+    c, cx, cy, _ = run(fixtures, [1], [False], [0], [box])
+    assert c.shape[-2:] == (100, 150)
+    kept = cx >= 0
+    assert (cx[kept] < 150).all() and (cy[kept] >= 0).all() and (cy[kept] < 100).all()
+    ev = fixtures['events_1']
+    gx, gy = ev[:, 0].astype(int), ev[:, 1].astype(int)
+    gt = fixtures['frames'][1:3].astype(np.float32)
+    assert (gt[:, 1:101, 2:152] == c).all()
+    mask = (gx >= 2) & (gx < 152) & (gy >= 1) & (gy < 101)
+    assert np.array_equal(kept, mask)
+    for i in range(2):
+        assert (c[i][cy[kept], cx[kept]] == gt[i][gy[mask], gx[mask]]).all()
+
+
+def test_dropped_events_are_ignored_by_the_voxeliser(fixtures):
+    """x = y = -1 slots contribute nothing: voxelising the augmented batch ==
+    voxelising its compacted form."""
+    from dvs_of_training_framework_amd.voxel import voxelize
+    _, _, _, out = run(fixtures, [1, 4], [True, False], [25.0, -10.0],
+                       [[2, 40, 128, 128], [100, 200, 128, 128]])
+    ev = out['events']
+    n = ev['x'].numel()
+    g = torch.Generator().manual_seed(0)
+    ev['timestamp'] = torch.sort(torch.rand(n, generator=g) * 0.04)[0].cuda()
+    ev['polarity'] = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).cuda()
+    t0, t1 = torch.zeros(2).cuda(), torch.full((2,), 0.04).cuda()
+    full = voxelize(ev, t0, t1, 2, 5, 128, 128)
+    keep = ev['x'] >= 0
+    assert 0 < int(keep.sum()) < n
+    comp = {k: v[keep] for k, v in ev.items()}
+    assert torch.equal(full, voxelize(comp, t0, t1, 2, 5, 128, 128))
