@@ -24,7 +24,9 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # see dvs_of_training_framework_amd/__init__.py
+
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
