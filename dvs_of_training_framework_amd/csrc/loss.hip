@@ -373,25 +373,17 @@ __global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, con
 // does not depend on which workgroup happens to be last.
 constexpr int NGROUP = 8;   // doubles per group record: 7 sums + pad
 
-__device__ __forceinline__ double block_sum(double v, double *sh, int tid)
-{
-    v = wave_sum(v);
-    __syncthreads();
-    if ((tid & (kWave - 1)) == 0) sh[tid >> 6] = v;
-    __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
 __global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, double *group,
                                                            int *counter, float *terms,
                                                            float *loss_out, float w0, float w1,
                                                            float w2, float loss_scale,
                                                            int write_oob)
 {
-    __shared__ double sh[NT / kWave];
+    constexpr int NW = NT / kWave;
+    __shared__ double sh[NW][7];
     __shared__ int s_last;
     __shared__ double s_sum[DVSOF_MAX_SCALES][6];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int k = blockIdx.x / P.N, n = blockIdx.x - k * P.N;
     {
         const ScaleDev &S = P.s[k];
@@ -401,45 +393,48 @@ __global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, doubl
 #pragma unroll
             for (int i = 0; i < 7; ++i) a[i] += (double)part[(size_t)b * NPART + i];
         }
+        // lanes -> waves -> workgroup: one barrier for all 7 sums
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            const double v = block_sum(a[i], sh, tid);
+            const double v = wave_sum(a[i]);
+            if (lane == 0) sh[wave][i] = v;
+        }
+        __syncthreads();
+        if (tid < 7) {
+            const double v = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
             // agent-scope (write-through) store: visible to the last workgroup on
             // any XCD without a full L2 write-back (__threadfence() costs ~20 us
             // here: the L2 is full of the step's dirty activations)
-            if (tid == 0)
-                __hip_atomic_store(&group[(size_t)blockIdx.x * NGROUP + i], v, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            if (i == 6 && tid == 0 && write_oob) P.oob[k * P.N + n] = (int)v;
+            __hip_atomic_store(&group[(size_t)blockIdx.x * NGROUP + tid], v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 6 && write_oob) P.oob[k * P.N + n] = (int)v;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged
         }
     }
-    if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores above have been acknowledged
+    __syncthreads();
+    if (tid == 0)
         s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
                  (int)gridDim.x - 1;
-    }
     __syncthreads();
     if (!s_last) return;
     // items (k, i): i < 5 global sums of photo + four smoothness directions,
-    // i == 5: border term = sum_n bs_n / (2 c_n N)  (utils/loss.py:101,113)
-    for (int kk = 0; kk < P.K; ++kk) {
-        double a[6] = {0, 0, 0, 0, 0, 0};
-        for (int nn = tid; nn < P.N; nn += NT) {
+    // i == 5: border term = sum_n bs_n / (2 c_n N)  (utils/loss.py:101,113).
+    // Item j belongs to wave j % NW: lane-strided over the samples + shuffle tree.
+    for (int item = wave; item < P.K * 6; item += NW) {
+        const int kk = item / 6, i = item - 6 * kk;
+        double a = 0;
+        for (int nn = lane; nn < P.N; nn += kWave) {
             const double *g = group + ((size_t)kk * P.N + nn) * NGROUP;
-            double r[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i)
-                r[i] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int i = 0; i < 5; ++i) a[i] += r[i];
-            const double bs = r[5], c = r[6];
-            if (c > 0) a[5] += bs / (2.0 * c * (double)P.N);
+            if (i < 5) {
+                a += __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const double bs = __hip_atomic_load(g + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double c = __hip_atomic_load(g + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c > 0) a += bs / (2.0 * c * (double)P.N);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double v = block_sum(a[i], sh, tid);
-            if (tid == 0) s_sum[kk][i] = v;
-        }
+        a = wave_sum(a);
+        if (lane == 0) s_sum[kk][i] = a;
     }
     __syncthreads();
     if (tid == 0) {

@@ -4,6 +4,7 @@ intercept of time(K) is the fixed cost of a launch (row setup, ring prologue,
 epilogue), the slope the cost per K step.  HIP events on the launch stream.
 
   python tools/conv_sweep.py fwd|dgrad B H W Cout stride [upsample]
+  python tools/conv_sweep.py wgrad  _ H W Cout stride upsample Cin     (sweeps the batch)
 """
 import ctypes
 import sys
@@ -37,6 +38,23 @@ def main():
     lib = C._lib.lib()
     print(f'{kind} B={B} {H}x{W} Cout={Cout} stride={stride} up={int(up)}')
     print(f'{"Cin":>5}{"K":>7}{"tile":>5}{"gen":>4}{"us":>9}{"exec TF/s":>11}')
+    if kind == 'wgrad':     # sweep the K of the weight-gradient GEMM (= pixels) through the batch
+        cin = int(sys.argv[8]) if len(sys.argv) > 8 else Cout
+        print(f'{"B":>5}{"pixels":>9}{"tile":>5}{"us":>9}{"exec TF/s":>11}')
+        for b in (1, 2, 4, 8, 16, 32, 64):
+            x = torch.randn(b, H, W, cin, device=dev)
+            d = C.make_desc([(x, cin, C.NHWC)], b, H, W, Cout, 3, stride, 1, up, C.ACT_RELU)
+            d._keepalive = (x,)
+            ho, wo = C.out_size(d)
+            g = torch.randn(b, ho, wo, Cout, device=dev)
+            dw = torch.empty(Cout, 3, 3, cin, device=dev)
+            db = torch.empty(Cout, device=dev)
+            us = timeit(lambda: C.conv_wgrad(d, g, dw, db))
+            tile = lib.dvsof_conv2d_tile_id(ctypes.byref(d), 2)
+            taps = 4 if up else 9
+            fl = 2.0 * b * ho * wo * Cout * cin * taps
+            print(f'{b:5d}{b * ho * wo:9d}{tile:5d}{us:9.1f}{fl / us / 1e6:11.1f}')
+        return
     for cin in (16, 32, 64, 128, 256, 512):
         x = torch.randn(B, H, W, cin, device=dev)
         w = torch.randn(Cout, 3, 3, cin, device=dev) * 0.05
