@@ -32,6 +32,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MATRIX_TFLOPS = 2516.6  # dense bf16 (v_mfma_f32_32x32x16_bf16), --dtype bf16 runs
 TILE_SHAPES = {
     'gconv': {1: '<2,2,2,2> 128x128', 2: '<2,2,2,1> 128x64', 3: '<2,2,1,1> 64x64',
               4: '<4,1,2,1> 256x32', 5: '<4,1,1,1> 128x32'},
@@ -62,6 +63,9 @@ def parse():
                    help='events per sample (default H*W, SURVEY 8d)')
     p.add_argument('--pool', type=int, default=2,
                    help='distinct resident batches cycled through')
+    p.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+                   help='conv matrix-core operand type (bf16: f32 storage and '
+                        'accumulation, operands rounded in registers)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--cpu-samples', type=int, default=2)
@@ -76,7 +80,8 @@ class Harness:
         from dvs_of_training_framework_amd.optim import FusedAdamW
         torch.manual_seed(1234)            # identical replicas
         self.a, self.device = a, device
-        self.model = Model(device, event_representation_depth=a.bins)
+        self.model = Model(device, event_representation_depth=a.bins,
+                           compute_dtype=getattr(a, 'dtype', 'f32'))
         self.model.train()
         self.opt = FusedAdamW(self.model.predictor.parameters(), lr=1e-3,
                               weight_decay=1e-4, amsgrad=True)
@@ -193,10 +198,12 @@ def measure_roofline(h, step_ms, steps=3):
     total_fl = sum(v[1] for v in agg.values())
     total_s = sum(v[2] for v in agg.values())
     total_x = sum(v[3] for v in agg.values())
+    peak = PEAK_BF16_MATRIX_TFLOPS if getattr(h.a, 'dtype', 'f32') == 'bf16' \
+        else PEAK_F32_MATRIX_TFLOPS
     roof = {'bound': 'mfma', 'kernel': dom,
             'achieved': round(fl / sec / 1e12, 2),
-            'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(fl / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+            'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(fl / sec / 1e12 / peak, 4),
             'traffic': pmc_traffic(dom),
             'traffic_source': 'profiles/round1/f_traffic_pmc.csv (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950; bytes/launch)',
             'avg_launch_us': round(sec / n * 1e6, 2),
@@ -204,13 +211,13 @@ def measure_roofline(h, step_ms, steps=3):
             # FLOPs actually issued to the matrix cores (sub-pixel / phased
             # decompositions change the count): the hardware-utilisation view
             'executed_tflops': round(xfl / sec / 1e12, 2),
-            'executed_frac': round(xfl / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+            'executed_frac': round(xfl / sec / 1e12 / peak, 4),
             # whole step: conv FLOPs of one step / measured step time (a lower
             # bound of the stack's rate: the step also voxelises, evaluates the
             # loss and runs the optimizer)
             'step_conv_tflops': round(total_fl / steps / step_ms / 1e9, 2),
             'step_conv_frac': round(total_fl / steps / step_ms / 1e9 /
-                                    PEAK_F32_MATRIX_TFLOPS, 4),
+                                    peak, 4),
             'step_conv_executed_tflops': round(total_x / steps / step_ms / 1e9, 2),
             # sums of per-launch durations: the backward runs weight gradients
             # on a second stream beside the data gradients, so launches overlap
@@ -218,7 +225,7 @@ def measure_roofline(h, step_ms, steps=3):
             'conv_stack_executed_tflops': round(total_x / total_s / 1e12, 2),
             'conv_stack_tflops': round(total_fl / total_s / 1e12, 2),
             'conv_stack_frac': round(total_fl / total_s / 1e12 /
-                                     PEAK_F32_MATRIX_TFLOPS, 4),
+                                     peak, 4),
             'per_kernel': {k: {kk: round(vv, 3) for kk, vv in v.items()}
                            for k, v in table.items()}}
     return roof
@@ -315,11 +322,13 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': a.dtype, 'data': 'synthetic',
             'config': {
                 'workload': f'EV_FlowNet {a.height}x{a.width}x{a.bins}-bin '
-                            f'synthetic events, batch {a.batch} per GPU, fp32 '
-                            '(BASELINE.json configs[1]); full step: voxelise + '
+                            f'synthetic events, batch {a.batch} per GPU, '
+                            + ('fp32 (BASELINE.json configs[1])' if a.dtype == 'f32' else
+                               'bf16 matrix-core operands, f32 storage/accumulate (configs[2] shape per GPU)')
+                            + '; full step: voxelise + '
                             'fwd + multi-scale loss + bwd + AdamW-amsgrad',
                 'global_batch': gb, 'events_per_sample':
                     a.events or a.height * a.width,

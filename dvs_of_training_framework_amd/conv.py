@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
     """dvsof_conv_desc_t"""
     _fields_ = [('src', Src * 3), ('nsrc', _i), ('B', _i), ('H', _i),
                 ('W', _i), ('upsample', _i), ('ksize', _i), ('stride', _i),
-                ('pad', _i), ('Cout', _i), ('act', _i)]
+                ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i)]
 
 
 class GradDst(ctypes.Structure):
@@ -55,8 +55,11 @@ _lib.register('dvsof_conv2d_dgrad_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])
 
 
+MFMA_F32, MFMA_BF16 = 0, 1
+
+
 def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
-              act=ACT_NONE):
+              act=ACT_NONE, mfma=MFMA_F32):
     """srcs: list of (tensor, C, layout)."""
     d = ConvDesc()
     d.nsrc = len(srcs)
@@ -67,7 +70,7 @@ def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
     d.B, d.H, d.W = B, H, W
     d.upsample = 1 if upsample else 0
     d.ksize, d.stride, d.pad = ksize, stride, pad
-    d.Cout, d.act = Cout, act
+    d.Cout, d.act, d.mfma = Cout, act, mfma
     return d
 
 

@@ -9,6 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // dword-aligned dwordx4 accesses (channel offsets such as 514*tap are only
 // 8-byte aligned).
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 enum { UP_NONE = 0, UP_NEAREST = 1, UP_ZERO = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2 };
@@ -56,6 +58,8 @@ struct GConvParams {
     int quad;           // rows ordered (b,y,x,dy,dx); epilogue sums the 2x2 quad
     int act;            // forward activation (ACT_*), applied after bias+addend
     int bwd_act;        // activation kind for actsrc
+    int mfma_bf16;      // 1: operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16
+                        // (f32 accumulate; every tensor stays f32 in memory)
     int ph_exact;       // phased stride-2 dgrad: phase (py,px) only has (1+py) x (1+px) non-zero
                         // taps; a kernel MAY skip the others (they multiply zero weights)
     int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step, 4 = loads from one L2-resident KiB
@@ -76,6 +80,7 @@ struct WGradParams {
     int g_sy, g_sx;
     int g_py, g_px;       // gout offsets of output phase (py, px)
     int nph, ph_pad, S;   // phases (1|4), pad shift per phase, K splits
+    int mfma_bf16;        // as in GConvParams
 };
 
 // Weight gradient of one flat concat member on the VALU (wgrad.hip), in the

@@ -42,7 +42,7 @@ struct KIt {
 // KSPLIT = 2: 8 waves; wave group g = wave/4 loads and multiplies sub-slice g of
 // every K-32 stage (two waves per SIMD even when the grid only offers one
 // workgroup per CU), the two accumulator sets are added through LDS at the end.
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT>
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, bool BF16>
 __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvParams P,
                                                                  const int nflat, const int nvec_all)
 {
@@ -154,16 +154,35 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     };
     auto mfma_slice = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
+        if constexpr (BF16) {
+            // the lane's two k-quads (8 values) of a 16-wide slice feed ONE
+            // 32x32x16 bf16 MFMA; A and B use the same k -> (lane, position) map
+            bf16x8 ab[TM], bb[TN];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int t = 0; t < TM; ++t)
+                ab[t] = __builtin_convertvector(
+                    __builtin_shufflevector(fa[buf][0][t], fa[buf][1][t], 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int t = 0; t < TN; ++t)
+                bb[t] = __builtin_convertvector(
+                    __builtin_shufflevector(fb[buf][0][t], fb[buf][1][t], 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[buf][j][tm][i], fb[buf][j][tn][i], acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                fa[buf][j][tm][i], fb[buf][j][tn][i], acc[tm][tn], 0, 0, 0);
+        }
     };
     auto compute1 = [&](const unsigned char *stage) {   // synchronous form (flat members)
         load_frags(std::integral_constant<int, 0>{}, stage);
@@ -414,23 +433,30 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT = 1>
-int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, bool BF16>
+int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
     constexpr int PA = BM / 16, PB0 = (BN + 15) / 16, PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
     constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * (sizeof(int) + sizeof(long long));
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT>,
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, BF16>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN, P.nph);
-    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT>), grid,
+    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, BF16>), grid,
                        dim3(CONV_NT * KSPLIT), LDS, st, P, nflat, nvec);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
+}
+
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT = 1>
+int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
+{
+    return P.mfma_bf16 ? launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, true>(P, nflat, nvec, st)
+                       : launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, false>(P, nflat, nvec, st);
 }
 
 }  // namespace

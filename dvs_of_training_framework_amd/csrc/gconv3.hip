@@ -430,7 +430,7 @@ bool gconv3_eligible(const GConvParams &P, int tile, long long max_src_bytes, lo
 {
     // measured (profiles/round1): v3 only beats v2 on the 256x32 tile, where
     // the A traffic per MFMA is highest; elsewhere its LDS footprint costs more
-    if (tile != 4) return false;
+    if (tile != 4 || P.mfma_bf16) return false;   // bf16-operand mode: gconv2 only
     if (P.up != UP_NONE || P.quad || P.ks * P.ks < 4) return false;
     bool any_vec = false;
     for (int s = 0; s < P.nsrc; ++s) {

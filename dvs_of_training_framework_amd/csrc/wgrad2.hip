@@ -20,7 +20,7 @@ constexpr int WNS = 4;  // ring stages
 constexpr unsigned WOOB = 0x80000000u;
 }  // namespace
 
-template <int WROWS, int WCOLS, int TM, int TN>
+template <int WROWS, int WCOLS, int TM, int TN, bool BF16>
 __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -177,11 +177,32 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
             _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                 \
                 _Pragma("unroll") for (int t = 0; t < TM; ++t) bsum[t] += fa[q][t];            \
         }                                                                                      \
-        _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                     \
+        if constexpr (BF16) {                                                                  \
+            /* the lane's 8 k values of the 16-pixel slice feed one 32x32x16 bf16 MFMA */      \
+            bf16x8 ab[TM], bb[TN];                                                             \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
+            {                                                                                  \
+                f32x8 v;                                                                       \
+                _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fa[q][t];                 \
+                ab[t] = __builtin_convertvector(v, bf16x8);                                    \
+            }                                                                                  \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t)                                     \
+            {                                                                                  \
+                f32x8 v;                                                                       \
+                _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fb[q][t];                 \
+                bb[t] = __builtin_convertvector(v, bf16x8);                                    \
+            }                                                                                  \
             _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                  \
                 _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] =                \
-                    __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][tm], fb[q][tn], acc[tm][tn], 0, \
-                                                         0, 0);                                \
+                    __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[tm], bb[tn], acc[tm][tn], 0, 0, \
+                                                            0);                                \
+        } else {                                                                               \
+            _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                 \
+                _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                              \
+                    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] =            \
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][tm], fb[q][tn],             \
+                                                             acc[tm][tn], 0, 0, 0);            \
+        }                                                                                      \
     }
 #define W2_STEP(U)                                                                          \
     {                                                                                       \
@@ -241,22 +262,29 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN>
-int launch_w2(const WGradParams &P, int ntiles, hipStream_t st)
+template <int WROWS, int WCOLS, int TM, int TN, bool BF16>
+int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
 {
     constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
     constexpr int PA0 = BMc / 16, PB = BN / 16, PA = PA0 + ((4 - (PA0 + PB) % 4) % 4);
     constexpr size_t LDS = (size_t)WNS * (PA + PB) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad2_kernel<WROWS, WCOLS, TM, TN>,
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid(ntiles, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
-    hipLaunchKernelGGL((wgrad2_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), LDS, st, P);
+    hipLaunchKernelGGL((wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16>), grid, dim3(CONV_NT), LDS, st, P);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
+}
+
+template <int WROWS, int WCOLS, int TM, int TN>
+int launch_w2(const WGradParams &P, int ntiles, hipStream_t st)
+{
+    return P.mfma_bf16 ? launch_w2x<WROWS, WCOLS, TM, TN, true>(P, ntiles, st)
+                       : launch_w2x<WROWS, WCOLS, TM, TN, false>(P, ntiles, st);
 }
 
 }  // namespace

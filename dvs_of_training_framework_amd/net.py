@@ -50,7 +50,8 @@ class VoxelGrid(nn.Module):
 class Model(nn.Module):
     def __init__(self, device, prefix_length=0, suffix_length=0,
                  max_sequence_length=1, dynamic_sample_length=False,
-                 event_representation_depth=9, activation=None):
+                 event_representation_depth=9, activation=None,
+                 compute_dtype='f32'):
         super().__init__()
         self.prefix_length = prefix_length
         self.suffix_length = suffix_length
@@ -58,7 +59,8 @@ class Model(nn.Module):
         self.dynamic_sample_length = dynamic_sample_length
         self.event_representation_depth = event_representation_depth
         self.quantization_layer = VoxelGrid(event_representation_depth)
-        self.predictor = Predictor(event_representation_depth, activation)
+        self.predictor = Predictor(event_representation_depth, activation,
+                                   compute_dtype)
         # strict=True reproduces the reference's host-side assertions (one
         # device sync per call); the train loop turns it off after step one.
         self.strict = True

@@ -106,7 +106,8 @@ class _PredictorFn(torch.autograd.Function):
 
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
-            d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act)
+            d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act,
+                            module.mfma)
             # prepared weights: sub-pixel phase kernels for the decoder, and
             # (when training) the data-gradient form, made once per step
             first = len(L) == 0       # voxel input needs no data gradient
@@ -276,10 +277,16 @@ class _PredictorFn(torch.autograd.Function):
 
 
 class Predictor(nn.Module):
-    def __init__(self, in_channels, activation=None):
+    def __init__(self, in_channels, activation=None, compute_dtype='f32'):
         super().__init__()
         self.in_channels = in_channels
         self.act = activation_id(activation)
+        # 'f32': exact f32 matrix cores.  'bf16': conv operands rounded to bf16
+        # in registers (v_mfma_f32_32x32x16_bf16), f32 accumulation; weights,
+        # activations, gradients and optimizer state all stay f32 in memory.
+        assert compute_dtype in ('f32', 'bf16'), compute_dtype
+        self.compute_dtype = compute_dtype
+        self.mfma = C.MFMA_BF16 if compute_dtype == 'bf16' else C.MFMA_F32
         self.reducer = None      # parallel.GradReducer for data parallelism
         chans = (in_channels,) + ENC_CH
         self.enc = nn.ModuleList(

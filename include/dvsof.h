@@ -259,6 +259,9 @@ typedef struct {
     int ksize, stride, pad;
     int Cout;
     int act; /* DVSOF_ACT_* */
+    int mfma; /* 0: f32 matrix cores (exact products); 1: operands rounded to
+                 bf16 in registers, v_mfma_f32_32x32x16_bf16, f32 accumulate.
+                 Every tensor stays f32 in memory either way. */
 } dvsof_conv_desc_t;
 
 /*

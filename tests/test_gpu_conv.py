@@ -76,10 +76,22 @@ def torch_fwd(xs, w, b, o, act, C, residual=None):
     return y, z
 
 
+# bf16 mode: operands rounded to bf16 (2^-9 relative) inside the MFMA kernels,
+# f32 accumulation and storage; bound on the error relative to the peak
+BF16_RTOL = 2e-2
+
+
+@pytest.mark.parametrize('mfma', ['f32', 'bf16'])
 @pytest.mark.parametrize('ci', range(len(CASES)))
-def test_conv_fwd_dgrad_wgrad(ci):
+def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     case = CASES[ci]
     C, xs, w, b, desc, act, o = build(case, seed=ci)
+    if mfma == 'bf16':
+        desc.mfma = C.MFMA_BF16
+        exact = close
+
+        def close(got, want):                      # noqa: F811
+            exact(got, want, BF16_RTOL)
     xs = [x.requires_grad_(True) for x in xs]
     w.requires_grad_(True)
     b.requires_grad_(True)
