@@ -63,7 +63,7 @@ def parse():
                    help='events per sample (default H*W, SURVEY 8d)')
     p.add_argument('--pool', type=int, default=2,
                    help='distinct resident batches cycled through')
-    p.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+    p.add_argument('--dtype', choices=('f32', 'bf16', 'bf16x3'), default='f32',
                    help='conv matrix-core operand type (bf16: f32 storage and '
                         'accumulation, operands rounded in registers)')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -198,7 +198,7 @@ def measure_roofline(h, step_ms, steps=3):
     total_fl = sum(v[1] for v in agg.values())
     total_s = sum(v[2] for v in agg.values())
     total_x = sum(v[3] for v in agg.values())
-    peak = PEAK_BF16_MATRIX_TFLOPS if getattr(h.a, 'dtype', 'f32') == 'bf16' \
+    peak = PEAK_BF16_MATRIX_TFLOPS if getattr(h.a, 'dtype', 'f32') != 'f32' \
         else PEAK_F32_MATRIX_TFLOPS
     roof = {'bound': 'mfma', 'kernel': dom,
             'achieved': round(fl / sec / 1e12, 2),
@@ -327,7 +327,7 @@ def main():
                 'workload': f'EV_FlowNet {a.height}x{a.width}x{a.bins}-bin '
                             f'synthetic events, batch {a.batch} per GPU, '
                             + ('fp32 (BASELINE.json configs[1])' if a.dtype == 'f32' else
-                               'bf16 matrix-core operands, f32 storage/accumulate (configs[2] shape per GPU)')
+                               f'{a.dtype} matrix-core operands, f32 storage/accumulate (configs[2] shape per GPU)')
                             + '; full step: voxelise + '
                             'fwd + multi-scale loss + bwd + AdamW-amsgrad',
                 'global_batch': gb, 'events_per_sample':

@@ -55,7 +55,7 @@ _lib.register('dvsof_conv2d_dgrad_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])
 
 
-MFMA_F32, MFMA_BF16 = 0, 1
+MFMA_F32, MFMA_BF16, MFMA_BF16X3 = 0, 1, 2
 
 
 def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,

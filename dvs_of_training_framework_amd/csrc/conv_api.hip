@@ -320,7 +320,7 @@ int head_blocks(long long total, int lpp)
 
 void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParams &P)
 {
-    P.mfma_bf16 = d->mfma == 1;
+    P.mfma_bf16 = (d->mfma == 1 || d->mfma == 2) ? d->mfma : 0;
     const int up = d->upsample ? 2 : 1;
     P.nsrc = d->nsrc;
     for (int i = 0; i < d->nsrc; ++i)
@@ -431,7 +431,7 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     P.M = d->B * Ho * Wo;
     P.quad = 0;
     P.act = d->act;
-    P.mfma_bf16 = d->mfma == 1;
+    P.mfma_bf16 = (d->mfma == 1 || d->mfma == 2) ? d->mfma : 0;
     P.bwd_act = ACT_NONE;
     P.nph = 1;
     P.ph_pad = 0;
@@ -479,7 +479,7 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
     P.N = Ctot;
     P.Cin_tot = d->Cout;
     P.act = ACT_NONE;
-    P.mfma_bf16 = d->mfma == 1;
+    P.mfma_bf16 = (d->mfma == 1 || d->mfma == 2) ? d->mfma : 0;
     P.bwd_act = bwd_act;
     P.nph = 1;
     P.ph_pad = 0;

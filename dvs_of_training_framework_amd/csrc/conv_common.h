@@ -59,7 +59,8 @@ struct GConvParams {
     int act;            // forward activation (ACT_*), applied after bias+addend
     int bwd_act;        // activation kind for actsrc
     int mfma_bf16;      // 1: operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16
-                        // (f32 accumulate; every tensor stays f32 in memory)
+                        // (f32 accumulate; every tensor stays f32 in memory);
+                        // 2: operands split hi + lo, three bf16 products (~2^-16 relative)
     int ph_exact;       // phased stride-2 dgrad: phase (py,px) only has (1+py) x (1+px) non-zero
                         // taps; a kernel MAY skip the others (they multiply zero weights)
     int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step, 4 = loads from one L2-resident KiB

@@ -42,7 +42,7 @@ struct KIt {
 // KSPLIT = 2: 8 waves; wave group g = wave/4 loads and multiplies sub-slice g of
 // every K-32 stage (two waves per SIMD even when the grid only offers one
 // workgroup per CU), the two accumulator sets are added through LDS at the end.
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, bool BF16>
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, int BF16>
 __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvParams P,
                                                                  const int nflat, const int nvec_all)
 {
@@ -154,23 +154,36 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     };
     auto mfma_slice = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if constexpr (BF16) {
+        if constexpr (BF16 != 0) {
             // the lane's two k-quads (8 values) of a 16-wide slice feed ONE
-            // 32x32x16 bf16 MFMA; A and B use the same k -> (lane, position) map
-            bf16x8 ab[TM], bb[TN];
+            // 32x32x16 bf16 MFMA; A and B use the same k -> (lane, position) map.
+            // BF16 == 2: split operands a = hi + lo (both bf16) and three products
+            // hi*hi + hi*lo + lo*hi: the dropped lo*lo term is 2^-16 relative
+            bf16x8 ab[TM], bb[TN], al[TM], bl[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t)
-                ab[t] = __builtin_convertvector(
-                    __builtin_shufflevector(fa[buf][0][t], fa[buf][1][t], 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
+            for (int t = 0; t < TM; ++t) {
+                const f32x8 v = __builtin_shufflevector(fa[buf][0][t], fa[buf][1][t], 0, 1, 2, 3, 4, 5, 6, 7);
+                ab[t] = __builtin_convertvector(v, bf16x8);
+                if constexpr (BF16 == 2)
+                    al[t] = __builtin_convertvector(v - __builtin_convertvector(ab[t], f32x8), bf16x8);
+            }
 #pragma unroll
-            for (int t = 0; t < TN; ++t)
-                bb[t] = __builtin_convertvector(
-                    __builtin_shufflevector(fb[buf][0][t], fb[buf][1][t], 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
+            for (int t = 0; t < TN; ++t) {
+                const f32x8 v = __builtin_shufflevector(fb[buf][0][t], fb[buf][1][t], 0, 1, 2, 3, 4, 5, 6, 7);
+                bb[t] = __builtin_convertvector(v, bf16x8);
+                if constexpr (BF16 == 2)
+                    bl[t] = __builtin_convertvector(v - __builtin_convertvector(bb[t], f32x8), bf16x8);
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+                for (int tn = 0; tn < TN; ++tn) {
+                    if constexpr (BF16 == 2) {   // small terms first
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    }
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+                }
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, bool BF16>
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, int BF16>
 int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
@@ -455,8 +468,9 @@ int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT = 1>
 int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
-    return P.mfma_bf16 ? launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, true>(P, nflat, nvec, st)
-                       : launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, false>(P, nflat, nvec, st);
+    if (P.mfma_bf16 == 2) return launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, 2>(P, nflat, nvec, st);
+    if (P.mfma_bf16 == 1) return launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, 1>(P, nflat, nvec, st);
+    return launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, 0>(P, nflat, nvec, st);
 }
 
 }  // namespace

@@ -20,7 +20,7 @@ constexpr int WNS = 4;  // ring stages
 constexpr unsigned WOOB = 0x80000000u;
 }  // namespace
 
-template <int WROWS, int WCOLS, int TM, int TN, bool BF16>
+template <int WROWS, int WCOLS, int TM, int TN, int BF16>
 __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -177,25 +177,38 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
             _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                 \
                 _Pragma("unroll") for (int t = 0; t < TM; ++t) bsum[t] += fa[q][t];            \
         }                                                                                      \
-        if constexpr (BF16) {                                                                  \
-            /* the lane's 8 k values of the 16-pixel slice feed one 32x32x16 bf16 MFMA */      \
-            bf16x8 ab[TM], bb[TN];                                                             \
+        if constexpr (BF16 != 0) {                                                             \
+            /* the lane's 8 k values of the 16-pixel slice feed one 32x32x16 bf16 MFMA;  */   \
+            /* BF16 == 2: hi/lo split, three products (see gconv2.hip)                    */   \
+            bf16x8 ab[TM], bb[TN], al[TM], bl[TN];                                             \
             _Pragma("unroll") for (int t = 0; t < TM; ++t)                                     \
             {                                                                                  \
                 f32x8 v;                                                                       \
                 _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fa[q][t];                 \
                 ab[t] = __builtin_convertvector(v, bf16x8);                                    \
+                if constexpr (BF16 == 2) al[t] = __builtin_convertvector(                      \
+                    v - __builtin_convertvector(ab[t], f32x8), bf16x8);                        \
             }                                                                                  \
             _Pragma("unroll") for (int t = 0; t < TN; ++t)                                     \
             {                                                                                  \
                 f32x8 v;                                                                       \
                 _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fb[q][t];                 \
                 bb[t] = __builtin_convertvector(v, bf16x8);                                    \
+                if constexpr (BF16 == 2) bl[t] = __builtin_convertvector(                      \
+                    v - __builtin_convertvector(bb[t], f32x8), bf16x8);                        \
             }                                                                                  \
             _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                  \
-                _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] =                \
-                    __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[tm], bb[tn], acc[tm][tn], 0, 0, \
-                                                            0);                                \
+                _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                              \
+            {                                                                                  \
+                if constexpr (BF16 == 2) {                                                     \
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                     \
+                        al[tm], bb[tn], acc[tm][tn], 0, 0, 0);                                 \
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                     \
+                        ab[tm], bl[tn], acc[tm][tn], 0, 0, 0);                                 \
+                }                                                                              \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[tm], bb[tn],          \
+                                                                      acc[tm][tn], 0, 0, 0);   \
+            }                                                                                  \
         } else {                                                                               \
             _Pragma("unroll") for (int q = 0; q < BK / 2; ++q)                                 \
                 _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                              \
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN, bool BF16>
+template <int WROWS, int WCOLS, int TM, int TN, int BF16>
 int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
 {
     constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
@@ -283,8 +296,9 @@ int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
 template <int WROWS, int WCOLS, int TM, int TN>
 int launch_w2(const WGradParams &P, int ntiles, hipStream_t st)
 {
-    return P.mfma_bf16 ? launch_w2x<WROWS, WCOLS, TM, TN, true>(P, ntiles, st)
-                       : launch_w2x<WROWS, WCOLS, TM, TN, false>(P, ntiles, st);
+    if (P.mfma_bf16 == 2) return launch_w2x<WROWS, WCOLS, TM, TN, 2>(P, ntiles, st);
+    if (P.mfma_bf16 == 1) return launch_w2x<WROWS, WCOLS, TM, TN, 1>(P, ntiles, st);
+    return launch_w2x<WROWS, WCOLS, TM, TN, 0>(P, ntiles, st);
 }
 
 }  // namespace

@@ -284,9 +284,13 @@ class Predictor(nn.Module):
         # 'f32': exact f32 matrix cores.  'bf16': conv operands rounded to bf16
         # in registers (v_mfma_f32_32x32x16_bf16), f32 accumulation; weights,
         # activations, gradients and optimizer state all stay f32 in memory.
-        assert compute_dtype in ('f32', 'bf16'), compute_dtype
+        # 'bf16x3': operands split into bf16 hi + lo, three products (error
+        # ~2^-16 per product instead of 2^-24): f32-like accuracy at the bf16
+        # matrix rate.
+        modes = {'f32': C.MFMA_F32, 'bf16': C.MFMA_BF16, 'bf16x3': C.MFMA_BF16X3}
+        assert compute_dtype in modes, compute_dtype
         self.compute_dtype = compute_dtype
-        self.mfma = C.MFMA_BF16 if compute_dtype == 'bf16' else C.MFMA_F32
+        self.mfma = modes[compute_dtype]
         self.reducer = None      # parallel.GradReducer for data parallelism
         chans = (in_channels,) + ENC_CH
         self.enc = nn.ModuleList(

@@ -260,8 +260,10 @@ typedef struct {
     int Cout;
     int act; /* DVSOF_ACT_* */
     int mfma; /* 0: f32 matrix cores (exact products); 1: operands rounded to
-                 bf16 in registers, v_mfma_f32_32x32x16_bf16, f32 accumulate.
-                 Every tensor stays f32 in memory either way. */
+                 bf16 in registers, v_mfma_f32_32x32x16_bf16, f32 accumulate;
+                 2: operands split into bf16 hi + lo, products hi*hi + hi*lo +
+                 lo*hi (the dropped lo*lo term is 2^-16 relative).
+                 Every tensor stays f32 in memory in all modes. */
 } dvsof_conv_desc_t;
 
 /*

@@ -81,17 +81,21 @@ def torch_fwd(xs, w, b, o, act, C, residual=None):
 BF16_RTOL = 2e-2
 
 
-@pytest.mark.parametrize('mfma', ['f32', 'bf16'])
+# bf16x3: hi/lo split operands, three products: ~2^-16 per product
+BF16X3_RTOL = 1e-4
+
+
+@pytest.mark.parametrize('mfma', ['f32', 'bf16', 'bf16x3'])
 @pytest.mark.parametrize('ci', range(len(CASES)))
 def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     case = CASES[ci]
     C, xs, w, b, desc, act, o = build(case, seed=ci)
-    if mfma == 'bf16':
-        desc.mfma = C.MFMA_BF16
-        exact = close
+    if mfma != 'f32':
+        desc.mfma = C.MFMA_BF16 if mfma == 'bf16' else C.MFMA_BF16X3
+        exact, tol = close, BF16_RTOL if mfma == 'bf16' else BF16X3_RTOL
 
         def close(got, want):                      # noqa: F811
-            exact(got, want, BF16_RTOL)
+            exact(got, want, tol)
     xs = [x.requires_grad_(True) for x in xs]
     w.requires_grad_(True)
     b.requires_grad_(True)

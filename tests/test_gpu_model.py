@@ -280,3 +280,22 @@ def test_bf16_operand_mode_tracks_the_f32_predictor():
         rel = float((p.grad - q.grad).norm()) / (float(p.grad.norm()) + 1e-12)
         cos = float((p.grad * q.grad).sum()) / (float(p.grad.norm() * q.grad.norm()) + 1e-12)
         assert rel <= 0.2 and cos >= 0.98, (rel, cos)
+
+
+def test_bf16x3_mode_is_f32_accurate():
+    """compute_dtype='bf16x3' (hi/lo split operands, three bf16 products) stays
+    inside the north star's 1e-3 relative parity budget with a wide margin."""
+    from dvs_of_training_framework_amd.predictor import Predictor
+    torch.manual_seed(12)
+    a = Predictor(5).cuda()
+    b = Predictor(5, compute_dtype='bf16x3').cuda()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, 5, 64, 64, device='cuda')
+    fa, fb = a(x), b(x)
+    seeds = [torch.randn_like(f) for f in fa]
+    torch.autograd.backward(fa, seeds)
+    torch.autograd.backward(fb, seeds)
+    for u, v in zip(fa, fb):
+        assert float((u - v).norm()) <= 1e-4 * float(u.norm())
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert float((p.grad - q.grad).norm()) <= 1e-3 * float(p.grad.norm()) + 1e-9
