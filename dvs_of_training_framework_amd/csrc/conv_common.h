@@ -130,6 +130,53 @@ __device__ __forceinline__ float act_bwd(float s, int act)
     return 1.f;
 }
 
+// One 16-wide K slice of a (TM*32) x (TN*32) wave tile from the lane's two
+// k-quads per operand.  MODE 0: eight exact f32 MFMAs per block; 1: operands
+// rounded to bf16, one 32x32x16 MFMA; 2: bf16 hi + lo split, three products.
+template <int MODE, int TM, int TN>
+__device__ __forceinline__ void mfma_k16(f32x16 (&acc)[TM][TN], const f32x4 (&a)[2][TM],
+                                         const f32x4 (&b)[2][TN])
+{
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][tm][i], b[j][tn][i],
+                                                                           acc[tm][tn], 0, 0, 0);
+    } else {
+        bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const f32x8 v = __builtin_shufflevector(a[0][t], a[1][t], 0, 1, 2, 3, 4, 5, 6, 7);
+            ah[t] = __builtin_convertvector(v, bf16x8);
+            if constexpr (MODE == 2)
+                al[t] = __builtin_convertvector(v - __builtin_convertvector(ah[t], f32x8), bf16x8);
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const f32x8 v = __builtin_shufflevector(b[0][t], b[1][t], 0, 1, 2, 3, 4, 5, 6, 7);
+            bh[t] = __builtin_convertvector(v, bf16x8);
+            if constexpr (MODE == 2)
+                bl[t] = __builtin_convertvector(v - __builtin_convertvector(bh[t], f32x8), bf16x8);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if constexpr (MODE == 2) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                }
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Epilogue shared by the MFMA convolution kernels.
 //

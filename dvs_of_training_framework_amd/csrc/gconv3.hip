@@ -25,7 +25,7 @@ constexpr int G3_NS = 4;   // weight ring stages
 constexpr unsigned G3_OOB = 0x80000000u;
 }  // namespace
 
-template <int WROWS, int WCOLS, int TM, int TN, int TH, int TW, int LAS>
+template <int WROWS, int WCOLS, int TM, int TN, int TH, int TW, int LAS, int BF16>
 __global__ __launch_bounds__(CONV_NT) void gconv3_kernel(const GConvParams P, const int nflat,
                                                          const int nchunks, const int npp,
                                                          const int patch_kb, const int tiles_x,
@@ -141,22 +141,17 @@ __global__ __launch_bounds__(CONV_NT) void gconv3_kernel(const GConvParams P, co
                 *(float *)(smem + r * 64 + ((((kk >> 2) ^ ((r >> 2) & 3))) << 4) + (kk & 3) * 4) = v;
             }
             __syncthreads();
+            {
+                f32x4 a[2][TM], b[2][TN];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x4 a[TM], b[TN];
+                for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int t = 0; t < TM; ++t)
-                    a[t] = *(const f32x4 *)(patch0 + ((wr * TM + t) * 32 + lrow) * 64 + (2 * j + lh) * 16);
+                    for (int t = 0; t < TM; ++t)
+                        a[j][t] = *(const f32x4 *)(patch0 + ((wr * TM + t) * 32 + lrow) * 64 + (2 * j + lh) * 16);
 #pragma unroll
-                for (int t = 0; t < TN; ++t) b[t] = *(const f32x4 *)(smem + b_off[t][j]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                a[tm][i], b[tn][i], acc[tm][tn], 0, 0, 0);
+                    for (int t = 0; t < TN; ++t) b[j][t] = *(const f32x4 *)(smem + b_off[t][j]);
+                }
+                mfma_k16<BF16, TM, TN>(acc, a, b);
             }
             ++done;
             f0 += BK;
@@ -327,12 +322,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv3_kernel(const GConvParams P, co
                     _Pragma("unroll") for (int t = 0; t < TN; ++t) b[j][t] =                     \
                         *(const f32x4 *)(smem + (U) * BSTAGE + b_off[t][j]);                     \
                 }                                                                                \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                    \
-                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
-                        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                        \
-                            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] =      \
-                                __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][tm][i], b[j][tn][i],   \
-                                                                     acc[tm][tn], 0, 0, 0);      \
+                mfma_k16<BF16, TM, TN>(acc, a, b);                                               \
             }                                                                                    \
             if (++c_kx == P.ks) {                                                                \
                 c_kx = 0;                                                                        \
@@ -393,23 +383,31 @@ bool g3_plan(const GConvParams &P, int tile, G3Plan &pl)
     return pl.lds <= 160 * 1024;
 }
 
-template <int WROWS, int WCOLS, int TM, int TN, int TH, int TW, int LAS>
-int launch3(const GConvParams &P, const G3Plan &pl, hipStream_t st)
+template <int WROWS, int WCOLS, int TM, int TN, int TH, int TW, int LAS, int BF16>
+int launch3x(const GConvParams &P, const G3Plan &pl, hipStream_t st)
 {
     constexpr int BN = WCOLS * TN * 32;
     static size_t attr_lds = 0;
     if (pl.lds > attr_lds) {
         DVSOF_HIP_TRY(hipFuncSetAttribute(
-            (const void *)gconv3_kernel<WROWS, WCOLS, TM, TN, TH, TW, LAS>,
+            (const void *)gconv3_kernel<WROWS, WCOLS, TM, TN, TH, TW, LAS, BF16>,
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
         attr_lds = pl.lds;
     }
     const int tiles_x = (P.Wo + TW - 1) / TW, tiles_y = (P.Ho + TH - 1) / TH;
     dim3 grid(tiles_x * tiles_y * P.B, (P.N + BN - 1) / BN, P.nph);
-    hipLaunchKernelGGL((gconv3_kernel<WROWS, WCOLS, TM, TN, TH, TW, LAS>), grid, dim3(CONV_NT), pl.lds,
+    hipLaunchKernelGGL((gconv3_kernel<WROWS, WCOLS, TM, TN, TH, TW, LAS, BF16>), grid, dim3(CONV_NT), pl.lds,
                        st, P, pl.nflat, pl.nchunks, pl.npp, pl.patch_kb, tiles_x, tiles_y);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
+}
+
+template <int WROWS, int WCOLS, int TM, int TN, int TH, int TW, int LAS>
+int launch3(const GConvParams &P, const G3Plan &pl, hipStream_t st)
+{
+    if (P.mfma_bf16 == 2) return launch3x<WROWS, WCOLS, TM, TN, TH, TW, LAS, 2>(P, pl, st);
+    if (P.mfma_bf16 == 1) return launch3x<WROWS, WCOLS, TM, TN, TH, TW, LAS, 1>(P, pl, st);
+    return launch3x<WROWS, WCOLS, TM, TN, TH, TW, LAS, 0>(P, pl, st);
 }
 
 template <int WROWS, int WCOLS, int TM, int TN, int TH, int TW>
@@ -430,7 +428,7 @@ bool gconv3_eligible(const GConvParams &P, int tile, long long max_src_bytes, lo
 {
     // measured (profiles/round1): v3 only beats v2 on the 256x32 tile, where
     // the A traffic per MFMA is highest; elsewhere its LDS footprint costs more
-    if (tile != 4 || P.mfma_bf16) return false;   // bf16-operand mode: gconv2 only
+    if (tile != 4) return false;
     if (P.up != UP_NONE || P.quad || P.ks * P.ks < 4) return false;
     bool any_vec = false;
     for (int s = 0; s < P.nsrc; ++s) {
