@@ -256,11 +256,15 @@ class _PredictorFn(torch.autograd.Function):
                 dst['addend2'] = g_skip[3]      # dec.0's skip into e4
             C.conv_dgrad(l1['desc'], wt(l1), g_t, [dst], act)
             gs = g_prev
-        # ---- encoder
+        # ---- encoder.  Its weight gradients are issued on the MAIN stream after
+        # the last data gradient: by then the second stream still holds the
+        # residual blocks' weight gradients, and the main stream would only
+        # wait for it -- this way both streams drain the tail together.
         gz = gs
+        deferred = []
         for i in (3, 2, 1, 0):
             lay = enc_l[i]
-            wgrad(lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i))
+            deferred.append((lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i)))
             if i == 0:
                 break
             below = enc_l[i - 1]
@@ -269,6 +273,12 @@ class _PredictorFn(torch.autograd.Function):
                          [dict(p=g_prev, addend=g_skip[i - 1],
                                actsrc=asrc(below))], act)
             gz = g_prev
+        for desc, g, gw, gb, unit in deferred:
+            if side is None or os.environ.get('DVSOF_ENC_WGRAD_SIDE'):
+                wgrad(desc, g, gw, gb, unit)
+            else:
+                C.conv_wgrad(desc, g, gw, gb)
+                finish(unit)
         if side is not None:
             main.wait_stream(side)
         del keep
