@@ -262,9 +262,14 @@ class _PredictorFn(torch.autograd.Function):
         # wait for it -- this way both streams drain the tail together.
         gz = gs
         deferred = []
+        n_side = int(os.environ.get('DVSOF_ENC_SIDE_FROM', '2'))
         for i in (3, 2, 1, 0):
             lay = enc_l[i]
-            deferred.append((lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i)))
+            item = (lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i))
+            if i >= n_side:
+                wgrad(*item)            # second stream (it is about to run dry)
+            else:
+                deferred.append(item)   # main stream, after the last data gradient
             if i == 0:
                 break
             below = enc_l[i - 1]
