@@ -70,26 +70,60 @@ class _FusedBase(torch.optim.Optimizer):
     def _launch(self, group, tables, step, plist):
         raise NotImplementedError
 
+    def _step_params(self, key, group, plist):
+        _lib.require_cuda(*plist)
+        for p in plist:
+            assert _dense(p) and not p.grad.is_sparse
+        steps = set()
+        for p in plist:
+            st = self._state(p)
+            st['step'] = int(st['step']) + 1
+            steps.add(st['step'])
+        assert len(steps) == 1, 'tensors of one group step together'
+        self._launch(group, self._table(key, plist), steps.pop(), plist)
+
+    # ---- update fused into the backward ------------------------------------
+    def fuse_into_backward(self, predictor):
+        """Update every gradient bucket of ``predictor`` as soon as its
+        gradients are final (after the all-reduce under data parallelism)
+        instead of in ``step()``: the HBM-bound update then runs beside the
+        MFMA-bound backward kernels.  Same arithmetic, same result; ``step()``
+        still has to be called and updates whatever is left.  Set
+        ``fused_active = False`` on micro-batches that only accumulate."""
+        self.fused_active = True
+        self._done = set()
+        self._group_of = {id(p): (gi, g) for gi, g in enumerate(self.param_groups)
+                          for p in g['params']}
+        predictor.bucket_hook = self._on_bucket
+
+    @torch.no_grad()
+    def _on_bucket(self, b, params):
+        if not getattr(self, 'fused_active', False):
+            return
+        by_group = {}
+        for p in params:
+            if id(p) in self._group_of and p.grad is not None:
+                gi, g = self._group_of[id(p)]
+                by_group.setdefault(gi, (g, []))[1].append(p)
+        for gi, (g, plist) in by_group.items():
+            self._step_params((gi, b), g, plist)
+            self._done.update(id(p) for p in plist)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        done = getattr(self, '_done', None)
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group['params'] if p.grad is not None]
+            plist = [p for p in group['params'] if p.grad is not None and
+                     not (done and id(p) in done)]
             if not plist:
                 continue
-            _lib.require_cuda(*plist)
-            for p in plist:
-                assert _dense(p) and not p.grad.is_sparse
-            steps = set()
-            for p in plist:
-                st = self._state(p)
-                st['step'] = int(st['step']) + 1
-                steps.add(st['step'])
-            assert len(steps) == 1, 'tensors of one group step together'
-            self._launch(group, self._table(gi, plist), steps.pop(), plist)
+            self._step_params(gi if not done else (gi, 'rest'), group, plist)
+        if done:
+            done.clear()
         return loss
 
 

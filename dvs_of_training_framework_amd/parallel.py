@@ -51,9 +51,18 @@ class GradReducer:
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
-    def bucket_ready(self, flat):
-        if not self.enabled or (self.world == 1 and
-                                os.environ.get('DVSOF_FORCE_DIST') != '1'):
+    def active(self):
+        """Does bucket_ready exchange anything?"""
+        return self.enabled and (self.world > 1 or
+                                 os.environ.get('DVSOF_FORCE_DIST') == '1')
+
+    def bucket_ready(self, flat, after=None):
+        """Average ``flat`` across ranks (asynchronously).  ``after``: callable
+        run once the average is enqueued -- on the exchange stream, behind the
+        collective (the fused optimizer update of this bucket)."""
+        if not self.active():
+            if after is not None:
+                after()
             return
         self.bytes_reduced += flat.numel() * flat.element_size()
         if flat.is_cuda:
@@ -64,18 +73,29 @@ class GradReducer:
                 side.wait_event(ready)
                 work = dist.all_reduce(flat, op=dist.ReduceOp.AVG,
                                        group=self.group, async_op=True)
+                if after is not None:
+                    work.wait()          # the exchange stream waits for the collective
+                    after()
             self.pending.append((work, flat, False))
+            self._touched = True
         else:   # gloo (CPU tests): SUM then scale
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM,
                                    group=self.group, async_op=True)
-            self.pending.append((work, flat, True))
+            self.pending.append((work, flat, True, after))
 
     def wait(self):
-        for work, flat, scale in self.pending:
+        for item in self.pending:
+            work, flat, scale = item[:3]
             work.wait()          # NCCL: the current stream waits, not the host
             if scale:
                 flat.div_(self.world)
+                if len(item) > 3 and item[3] is not None:
+                    item[3]()
         self.pending = []
+        if getattr(self, '_touched', False) and self._side is not None:
+            # updates enqueued behind the collectives on the exchange stream
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._touched = False
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -396,12 +396,22 @@ class Predictor(nn.Module):
                     p.grad = views[i]
             b = unit_bucket[unit]
             remaining[b] -= 1
-            if remaining[b] == 0 and reducer is not None:
+            if remaining[b] != 0:
+                return
+            hook = getattr(self, 'bucket_hook', None)    # optim.fuse_into_backward
+            after = None
+            if hook is not None:
+                bparams = [params[i] for u in self.BUCKETS[b]
+                           for i in self.UNIT_PARAMS[u]]
+                after = lambda: hook(b, bparams)            # noqa: E731
+            if reducer is not None and reducer.active():
                 owned = all(params[i].grad.data_ptr() == views[i].data_ptr()
                             for u in self.BUCKETS[b]
                             for i in self.UNIT_PARAMS[u])
                 assert owned, 'DP needs .grad to live in the bucket buffers'
-                reducer.bucket_ready(flats[b])
+                reducer.bucket_ready(flats[b], after)
+            elif after is not None:
+                after()
         return targets, finish
 
     def param_list(self):

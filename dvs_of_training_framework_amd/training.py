@@ -154,6 +154,8 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
         is_step_boundary = global_step % accumulation_steps == 0
         if reducer is not None:
             reducer.enabled = is_step_boundary
+        if hasattr(optimizer, 'fused_active'):    # optim.fuse_into_backward
+            optimizer.fused_active = is_step_boundary
         loss, (smoothness, photometric, out_reg), tags = process_minibatch(
             model, batch, timers, device, is_raw, evaluator, weights)
         loss /= accumulation_steps

@@ -328,3 +328,31 @@ def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses))
     assert np.mean(losses[-5:]) < 0.97 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+
+
+@pytest.mark.parametrize('opt_name', ['adamw', 'ranger'])
+def test_optimizer_fused_into_backward_is_the_same_update(opt_name):
+    """optim.fuse_into_backward: buckets are updated during the backward; the
+    weights after step() are bit-identical to the plain step()."""
+    from dvs_of_training_framework_amd.optim import FusedAdamW, FusedRanger
+    from dvs_of_training_framework_amd.predictor import Predictor
+
+    def run(fused):
+        torch.manual_seed(21)
+        net = Predictor(5).cuda()
+        opt = FusedAdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True) \
+            if opt_name == 'adamw' else FusedRanger(net.parameters(), lr=1e-3)
+        if fused:
+            opt.fuse_into_backward(net)
+        g = torch.Generator(device='cuda').manual_seed(3)
+        for it in range(3):
+            x = torch.randn(2, 5, 64, 64, device='cuda', generator=g)
+            flows = net(x)
+            seeds = [torch.randn(f.shape, device='cuda', generator=g) for f in flows]
+            torch.autograd.backward(flows, seeds)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        return [p.detach().clone() for p in net.parameters()]
+    a, b = run(False), run(True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
