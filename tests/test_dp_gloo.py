@@ -55,11 +55,29 @@ def _worker(rank, world, port, q):
     for unit in [u for b in net.BUCKETS for u in b]:
         finish(unit)
     npend = len(reducer.pending)
+    # bucket hook (optim.fuse_into_backward): runs after the average, sees it
+    seen = []
+    net.bucket_hook = lambda b, ps: seen.append((b, float(ps[0].grad.flatten()[0])))
     reducer.wait()
+    net.bucket_hook = None
     want = sum(11.0 * (k + 1) for k in range(world)) / world
     ok = all(torch.allclose(p.grad, torch.full_like(p, want)) for p in params)
     layout = all(p.grad.stride() == p.stride() for p in params)
-    q.put((rank, same, quiet, npend, ok, layout, reducer.bytes_reduced))
+    # the hook was installed after the collectives were issued: exercise the
+    # issue-time path too
+    reducer.enabled = True
+    net.bucket_hook = lambda b, ps: seen.append((b, float(ps[0].grad.flatten()[0])))
+    for p in params:
+        p.grad = None
+    targets, finish = net._grad_targets(params)
+    for t in targets:
+        t.fill_(float(rank + 1))
+    for unit in [u for b in net.BUCKETS for u in b]:
+        finish(unit)
+    reducer.wait()
+    hook_ok = sorted(b for b, _ in seen) == list(range(8)) and \
+        all(abs(v - sum(k + 1.0 for k in range(world)) / world) < 1e-6 for _, v in seen)
+    q.put((rank, same, quiet, npend, ok and hook_ok, layout, reducer.bytes_reduced))
     dist.destroy_process_group()
 
 
