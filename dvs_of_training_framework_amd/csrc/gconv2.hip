@@ -117,6 +117,12 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // wave tiles of ONE 32x32 block: a second accumulator for the odd k-quads
+    // halves the length of the dependent MFMA chain
+    constexpr bool DUAL = (TM * TN == 1) && (BF16 == 0);
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
     // fragment read addresses (bytes inside a stage): row R, k-quad q = 2j + h
     // lives in slot q ^ ((R>>2)&3)
@@ -184,6 +190,14 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                     }
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[tm], bb[tn], acc[tm][tn], 0, 0, 0);
                 }
+        } else if constexpr (DUAL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][0][0][i], fb[buf][0][0][i],
+                                                                 acc[0][0], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][1][0][i], fb[buf][1][0][i], acc2, 0,
+                                                            0, 0);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -417,6 +431,10 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         }
     }
 
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
+    }
     if (KSPLIT == 2) {   // add the second wave group's accumulators (ring memory is free now)
         __syncthreads();
         float *xch = (float *)smem + (size_t)wave * (TM * TN * 16 * 64);
