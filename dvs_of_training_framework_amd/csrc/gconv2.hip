@@ -406,6 +406,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                         auto step = [&](auto curc) {
                             constexpr int cur = decltype(curc)::value;
                             if (sub + 1 < KPW) {
+                                if (!(P.dbg & 16))
                                 load_frags(std::integral_constant<int, cur ^ 1>{},
                                            stage + (sub + 1 + wgrp * KPW) * SUB);
                             } else if (s + 1 < nvec) {
@@ -416,8 +417,9 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                                 }
                                 // every wave holds its stage-s fragments in registers: slot u is free
-                                __builtin_amdgcn_s_barrier();
-                                if (s + NS < nvec) issue(u);
+                                if (!(P.dbg & 32)) __builtin_amdgcn_s_barrier();
+                                if (s + NS < nvec && !(P.dbg & 8)) issue(u);
+                                if (!(P.dbg & 16))
                                 load_frags(std::integral_constant<int, cur ^ 1>{},
                                            smem + ((u + 1) % NS) * STAGE + wgrp * KPW * SUB);
                             }
