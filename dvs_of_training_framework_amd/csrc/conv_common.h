@@ -64,7 +64,8 @@ struct GConvParams {
     int ph_exact;       // phased stride-2 dgrad: phase (py,px) only has (1+py) x (1+px) non-zero
                         // taps; a kernel MAY skip the others (they multiply zero weights)
     int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step, 4 = loads from one L2-resident KiB,
-                        // 8 = no DMA in the loop, 16 = no fragment reads, 32 = no barrier
+                        // 8 = no DMA in the loop, 16 = no fragment reads, 32 = no barrier,
+                        // 128 = every K step re-reads chunk 0 (cache-resident footprint)
 };
 
 // Weight-gradient problem (wgrad.hip)

@@ -337,8 +337,10 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 #pragma unroll
             for (int sub0 = 0; sub0 < KPW; ++sub0) {
                 const int sub = sub0 + wgrp * KPW;
-                const int a_soff = __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
-                const int b_soff = __builtin_amdgcn_readfirstlane(
+                // dbg 128: every K step re-reads the first chunk (true 64-B-segment access
+                // pattern, cache-resident footprint)
+                const int a_soff = (P.dbg & 128) ? 0 : __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
+                const int b_soff = (P.dbg & 128) ? 0 : __builtin_amdgcn_readfirstlane(
                     ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff + it_c0 + sub * BK) * 4);
                 unsigned char *st = smem + stage_idx * STAGE + sub * SUB;
 #pragma unroll

@@ -35,7 +35,7 @@ def main():
         h.step()
     pr.disable()
     torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
+    pstats.Stats(pr).sort_stats('tottime').print_stats(28)
 
 
 if __name__ == '__main__':
