@@ -180,22 +180,37 @@ def measure_roofline(h, step_ms, steps=3):
                             e0, e1, executed_flops(desc, kind)))
             return out
         return inner
-    C.conv_fwd = wrap(orig[0], 0, 'gconv')
-    C.conv_dgrad = wrap(orig[1], 1, 'gconv')
-    C.conv_wgrad = wrap(orig[2], 2, 'wgrad')
+    def collect():
+        del records[:]
+        C.conv_fwd = wrap(orig[0], 0, 'gconv')
+        C.conv_dgrad = wrap(orig[1], 1, 'gconv')
+        C.conv_wgrad = wrap(orig[2], 2, 'wgrad')
+        try:
+            for _ in range(steps):
+                h.step()
+            torch.cuda.synchronize()
+        finally:
+            C.conv_fwd, C.conv_dgrad, C.conv_wgrad = orig
+        out = {}
+        for name, fl, e0, e1, xfl in records:
+            d = out.setdefault(name, [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += e0.elapsed_time(e1) * 1e-3
+            d[3] += xfl
+        return out
+    agg = collect()             # as timed: two backward streams, launches overlap
+    # the same launches one at a time (second backward stream off): what a kernel
+    # does when it has the GPU to itself
+    prev = os.environ.get('DVSOF_WGRAD_STREAM')
+    os.environ['DVSOF_WGRAD_STREAM'] = '0'
     try:
-        for _ in range(steps):
-            h.step()
-        torch.cuda.synchronize()
+        alone = collect()
     finally:
-        C.conv_fwd, C.conv_dgrad, C.conv_wgrad = orig
-    agg = {}
-    for name, fl, e0, e1, xfl in records:
-        d = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-        d[0] += 1
-        d[1] += fl
-        d[2] += e0.elapsed_time(e1) * 1e-3
-        d[3] += xfl
+        if prev is None:
+            del os.environ['DVSOF_WGRAD_STREAM']
+        else:
+            os.environ['DVSOF_WGRAD_STREAM'] = prev
     table = {k: dict(launches=v[0] // steps, gflop_per_step=v[1] / steps / 1e9,
                      ms_per_step=v[2] / steps * 1e3,
                      tflops=v[1] / v[2] / 1e12,
@@ -214,6 +229,14 @@ def measure_roofline(h, step_ms, steps=3):
             'traffic': pmc_traffic(dom),
             'traffic_source': 'profiles/round1/f_traffic_pmc.csv (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950; bytes/launch)',
             'avg_launch_us': round(sec / n * 1e6, 2),
+            # the dominant kernel with the second backward stream switched off
+            # (no other kernel on the GPU): same launches, same inputs
+            'single_stream': {
+                'achieved': round(alone[dom][1] / alone[dom][2] / 1e12, 2),
+                'frac': round(alone[dom][1] / alone[dom][2] / 1e12 / peak, 4),
+                'avg_launch_us': round(alone[dom][2] / alone[dom][0] * 1e6, 2),
+                'conv_stack_tflops': round(sum(v[1] for v in alone.values()) /
+                                           sum(v[2] for v in alone.values()) / 1e12, 2)},
             'gflop_per_launch': round(fl / n / 1e9, 3),
             # FLOPs actually issued to the matrix cores (sub-pixel / phased
             # decompositions change the count): the hardware-utilisation view
