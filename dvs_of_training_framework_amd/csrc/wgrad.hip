@@ -472,15 +472,27 @@ __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *
             __syncthreads();
             if (pl < RP && cbase + cl < P.Cout) {
                 const int np = (int)((p1 - base) < FLAT_PIX ? (p1 - base) : FLAT_PIX);
-                for (int p = pl; p < np; p += RP) {
-                    const float g = P.gout[(size_t)(base + p) * P.Cout + cbase + cl];
+                // eight gout values in flight per thread (one dependent load per
+                // pixel left the loop waiting on memory: 67 us for 33 MB)
+                for (int p0b = pl; p0b < np; p0b += 8 * RP) {
+                    float g[8];
 #pragma unroll
-                    for (int i = 0; i < NC4; i += 4) {
-                        const f32x4 x = *(const f32x4 *)&xs[p][i];
-                        acc[i] = fmaf(g, x[0], acc[i]);
-                        acc[i + 1] = fmaf(g, x[1], acc[i + 1]);
-                        acc[i + 2] = fmaf(g, x[2], acc[i + 2]);
-                        acc[i + 3] = fmaf(g, x[3], acc[i + 3]);
+                    for (int u = 0; u < 8; ++u) {
+                        const int p = p0b + u * RP;
+                        g[u] = p < np ? P.gout[(size_t)(base + p) * P.Cout + cbase + cl] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int p = p0b + u * RP;
+                        if (p >= np) break;
+#pragma unroll
+                        for (int i = 0; i < NC4; i += 4) {
+                            const f32x4 x = *(const f32x4 *)&xs[p][i];
+                            acc[i] = fmaf(g[u], x[0], acc[i]);
+                            acc[i + 1] = fmaf(g[u], x[1], acc[i + 1]);
+                            acc[i + 2] = fmaf(g[u], x[2], acc[i + 2]);
+                            acc[i + 3] = fmaf(g[u], x[3], acc[i + 3]);
+                        }
                     }
                 }
             }
