@@ -323,7 +323,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                 new_tap = false;
 #pragma unroll
                 for (int i = 0; i < NSLOT; ++i) {
-                    if (wave + 4 * i < PA) {
+                    if (i < PA / 4) {
                         const int Y = sy_[i] + it_ky, X = sx_[i] + it_kx;
                         bool ok = ((unsigned)Y < (unsigned)P.Hv) & ((unsigned)X < (unsigned)P.Wv);
                         if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
@@ -348,9 +348,12 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                     const int p = wave + 4 * i;     // SGPR
                     __attribute__((address_space(3))) void *dst =
                         (__attribute__((address_space(3))) void *)(st + p * 1024);
+                    // PA is a multiple of 4 and wave < 4: slot i holds an A piece iff
+                    // i < PA / 4 (compile-time: no scalar compare + branch per load)
+                    static_assert(PA % 4 == 0, "A pieces per wave");
                     if (P.dbg & 4) {   // timing probe: every load hits the same few KiB (L2-resident)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, slot_kq4[i] + (lane >> 2) * 64, 0, 0, 0);
-                    } else if (p < PA)
+                    } else if (i < PA / 4)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, dst, 16, voff[i], a_soff, 0, 0);
                     else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, voff[i], b_soff, 0, 0);
@@ -397,42 +400,54 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         __builtin_amdgcn_s_barrier();
         load_frags(std::integral_constant<int, 0>{}, smem + wgrp * KPW * SUB);
 
-        for (int s0 = 0; s0 < nvec; s0 += NS) {
+        // The K loop in two parts: a steady part (every range test of a stage is
+        // known to hold: no scalar compares / branches, no probes) and the last
+        // stages with the tests.  STEADY is a compile-time flag of the stage body.
+        auto stage_body = [&](auto steadyc, auto uc, const int s) {
+            constexpr bool STEADY = decltype(steadyc)::value;
+            constexpr int u = decltype(uc)::value;
+            if (!STEADY && !(s < nvec)) return;
 #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                const int s = s0 + u;
-                if (s < nvec) {
-#pragma unroll
-                    for (int sub = 0; sub < KPW; ++sub) {
-                        const unsigned char *stage = smem + u * STAGE;
-                        auto step = [&](auto curc) {
-                            constexpr int cur = decltype(curc)::value;
-                            if (sub + 1 < KPW) {
-                                if (!(P.dbg & 16))
-                                load_frags(std::integral_constant<int, cur ^ 1>{},
-                                           stage + (sub + 1 + wgrp * KPW) * SUB);
-                            } else if (s + 1 < nvec) {
-                                // stage s+1 has landed when at most the younger stages' loads remain
-                                if (s + NS - 1 < nvec) {
-                                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * LPW) : "memory");
-                                } else {
-                                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                                }
-                                // every wave holds its stage-s fragments in registers: slot u is free
-                                if (!(P.dbg & 32)) __builtin_amdgcn_s_barrier();
-                                if (s + NS < nvec && !(P.dbg & 8)) issue(u);
-                                if (!(P.dbg & 16))
-                                load_frags(std::integral_constant<int, cur ^ 1>{},
-                                           smem + ((u + 1) % NS) * STAGE + wgrp * KPW * SUB);
-                            }
-                            mfma_slice(std::integral_constant<int, cur>{});
-                        };
-                        if ((u * KPW + sub) & 1) step(std::integral_constant<int, 1>{});
-                        else step(std::integral_constant<int, 0>{});
+            for (int sub = 0; sub < KPW; ++sub) {
+                const unsigned char *stage = smem + u * STAGE;
+                auto step = [&](auto curc) {
+                    constexpr int cur = decltype(curc)::value;
+                    if (sub + 1 < KPW) {
+                        if (STEADY || !(P.dbg & 16))
+                            load_frags(std::integral_constant<int, cur ^ 1>{},
+                                       stage + (sub + 1 + wgrp * KPW) * SUB);
+                    } else if (STEADY || s + 1 < nvec) {
+                        // stage s+1 has landed when at most the younger stages' loads remain
+                        if (STEADY || s + NS - 1 < nvec) {
+                            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * LPW) : "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        }
+                        // every wave holds its stage-s fragments in registers: slot u is free
+                        if (STEADY || !(P.dbg & 32)) __builtin_amdgcn_s_barrier();
+                        if (STEADY || (s + NS < nvec && !(P.dbg & 8))) issue(u);
+                        if (STEADY || !(P.dbg & 16))
+                            load_frags(std::integral_constant<int, cur ^ 1>{},
+                                       smem + ((u + 1) % NS) * STAGE + wgrp * KPW * SUB);
                     }
-                }
+                    mfma_slice(std::integral_constant<int, cur>{});
+                };
+                if ((u * KPW + sub) & 1) step(std::integral_constant<int, 1>{});
+                else step(std::integral_constant<int, 0>{});
             }
-        }
+        };
+        auto ring_turn = [&](auto steadyc, const int s0) {
+            stage_body(steadyc, std::integral_constant<int, 0>{}, s0);
+            if constexpr (NS > 1) stage_body(steadyc, std::integral_constant<int, 1>{}, s0 + 1);
+            if constexpr (NS > 2) stage_body(steadyc, std::integral_constant<int, 2>{}, s0 + 2);
+            if constexpr (NS > 3) stage_body(steadyc, std::integral_constant<int, 3>{}, s0 + 3);
+            static_assert(NS <= 4, "ring turns are written out for up to 4 stages");
+        };
+        // steady turns: s0 + NS - 1 + NS < nvec for the last stage of the turn
+        const int nsteady = (P.dbg != 0 || nvec < 2 * NS) ? 0 : (nvec - 2 * NS + 1) / NS * NS;
+        int s0 = 0;
+        for (; s0 < nsteady; s0 += NS) ring_turn(std::true_type{}, s0);
+        for (; s0 < nvec; s0 += NS) ring_turn(std::false_type{}, s0);
     }
 
     if constexpr (DUAL) {
