@@ -318,7 +318,8 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         __amdgpu_buffer_rsrc_t ares =
             __builtin_amdgcn_make_buffer_rsrc((void *)P.src[it_s].p, 0, 0x7fffffff, 0x00020000);
 
-        auto issue = [&](int stage_idx) {
+        auto issue_impl = [&](auto probec, int stage_idx) {
+            constexpr bool PROBE = decltype(probec)::value;   // timing probes compiled in?
             if (new_tap) {  // per-lane offsets of the A slots for this (member, tap)
                 new_tap = false;
 #pragma unroll
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                 const int sub = sub0 + wgrp * KPW;
                 // dbg 128: every K step re-reads the first chunk (true 64-B-segment access
                 // pattern, cache-resident footprint)
-                const int a_soff = (P.dbg & 128) ? 0 : __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
-                const int b_soff = (P.dbg & 128) ? 0 : __builtin_amdgcn_readfirstlane(
+                const int a_soff = (PROBE && (P.dbg & 128)) ? 0 : __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
+                const int b_soff = (PROBE && (P.dbg & 128)) ? 0 : __builtin_amdgcn_readfirstlane(
                     ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff + it_c0 + sub * BK) * 4);
                 unsigned char *st = smem + stage_idx * STAGE + sub * SUB;
 #pragma unroll
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                     // PA is a multiple of 4 and wave < 4: slot i holds an A piece iff
                     // i < PA / 4 (compile-time: no scalar compare + branch per load)
                     static_assert(PA % 4 == 0, "A pieces per wave");
-                    if (P.dbg & 4) {   // timing probe: every load hits the same few KiB (L2-resident)
+                    if (PROBE && (P.dbg & 4)) {   // timing probe: every load hits the same few KiB (L2-resident)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, slot_kq4[i] + (lane >> 2) * 64, 0, 0, 0);
                     } else if (i < PA / 4)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, dst, 16, voff[i], a_soff, 0, 0);
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         static_assert((NS * KPW) % 2 == 0, "static fragment-buffer parity");
 #pragma unroll
         for (int u = 0; u < NS; ++u)
-            if (u < nvec) issue(u);
+            if (u < nvec) issue_impl(std::true_type{}, u);
         if (nvec >= NS) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * LPW) : "memory");
         } else {
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                         }
                         // every wave holds its stage-s fragments in registers: slot u is free
                         if (STEADY || !(P.dbg & 32)) __builtin_amdgcn_s_barrier();
-                        if (STEADY || (s + NS < nvec && !(P.dbg & 8))) issue(u);
+                        if constexpr (STEADY) issue_impl(std::false_type{}, u);
+                        else if (s + NS < nvec && !(P.dbg & 8)) issue_impl(std::true_type{}, u);
                         if (STEADY || !(P.dbg & 16))
                             load_frags(std::integral_constant<int, cur ^ 1>{},
                                        smem + ((u + 1) % NS) * STAGE + wgrp * KPW * SUB);
