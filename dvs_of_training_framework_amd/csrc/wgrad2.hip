@@ -231,17 +231,35 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
             W2_COMPUTE(U)                                                                   \
         }                                                                                   \
     }
+    // steady form: every range test of the step is known to hold
+#define W2_STEADY(U)                                                                        \
+    {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WNS - 2) * LPW) : "memory");              \
+        __builtin_amdgcn_s_barrier();                                                       \
+        issue(((U) + WNS - 1) % WNS);                                                       \
+        W2_COMPUTE(U)                                                                       \
+    }
 
 #pragma unroll
     for (int u = 0; u < WNS - 1; ++u)
         if (u < nsteps) issue(u);
     static_assert(WNS == 4, "the ring below is written out for 4 stages");
-    for (int s0 = 0; s0 < nsteps; s0 += WNS) {
+    // steady turns: st + WNS - 1 < nsteps for the last step of the turn
+    const int nsteady = nsteps < 2 * WNS ? 0 : (nsteps - 2 * WNS + 2) / WNS * WNS;
+    int s0 = 0;
+    for (; s0 < nsteady; s0 += WNS) {
+        W2_STEADY(0)
+        W2_STEADY(1)
+        W2_STEADY(2)
+        W2_STEADY(3)
+    }
+    for (; s0 < nsteps; s0 += WNS) {
         W2_STEP(0)
         W2_STEP(1)
         W2_STEP(2)
         W2_STEP(3)
     }
+#undef W2_STEADY
 #undef W2_STEP
 #undef W2_COMPUTE
 #undef DS_READ
