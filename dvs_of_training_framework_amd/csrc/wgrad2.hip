@@ -100,15 +100,22 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
         0x00020000);
     const long long g_ph = (long long)phy * P.g_py + (long long)phx * P.g_px;
 
-    // 16-pixel group -> (b, oy, ox0), all scalar
+    // 16-pixel group -> (b, oy, ox0), all scalar.  The byte offsets of the row
+    // the group is in are kept (recomputed on row / image wraps only); inside a
+    // row a step costs two scalar multiply-adds instead of two 64-bit chains.
     int g_ox = kbeg % Wo, g_oy = (kbeg / Wo) % Ho, g_b = kbeg / (Wo * Ho);
+    int a_row = 0, b_row = 0;
+    auto row_bases = [&]() {
+        a_row = (int)(((long long)g_b * g_sb + (long long)g_oy * g_sy + g_ph) * 4);
+        b_row = (int)(((long long)g_b * s_sb + (long long)(g_oy * stride) * s_sy) * 4);
+    };
+    row_bases();
+    const int a_px = g_sx * 4, b_px = stride * s_sx * 4;
 
     auto issue = [&](int stage_idx) {
-        const int a_soff = __builtin_amdgcn_readfirstlane(
-            (int)(((long long)g_b * g_sb + (long long)g_oy * g_sy + (long long)g_ox * g_sx + g_ph) * 4));
+        const int a_soff = __builtin_amdgcn_readfirstlane(a_row + g_ox * a_px);
         const int gy = g_oy * stride, gx = g_ox * stride;
-        const int b_soff = __builtin_amdgcn_readfirstlane(
-            (int)(((long long)g_b * s_sb + (long long)gy * s_sy + (long long)gx * s_sx) * 4));
+        const int b_soff = __builtin_amdgcn_readfirstlane(b_row + g_ox * b_px);
         unsigned char *st = smem + stage_idx * STAGE;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
                 g_oy = 0;
                 ++g_b;
             }
+            row_bases();
         }
     };
 
