@@ -49,14 +49,16 @@ def test_quantize_dataset_groups_files_and_round_trips():
             got.append(dec)
     assert len(got) == 5
     for g, w, b in zip(got, want, batches(5, B, H, W)):
-        assert torch.equal(g['data'], w)
+        # float atomics: two voxelisations of the same events agree to the last
+        # bits of the accumulation order, not bit for bit
+        assert torch.allclose(g['data'], w, rtol=0, atol=1e-5)
         assert torch.equal(g['timestamps'], b['timestamps'])
         assert torch.equal(g['images'], b['images'].to(torch.uint8).float())
 
 
 def test_quantized_batch_trains_like_the_raw_batch():
     """process_minibatch(is_raw=False) on the offline grid == is_raw=True on
-    the events (same loss, bit for bit: the grid is the same tensor)."""
+    the events (same loss up to the voxeliser's accumulation order)."""
     from dvs_of_training_framework_amd.loss import init_losses
     from dvs_of_training_framework_amd.net import Model
     from dvs_of_training_framework_amd.quantize import (iterate_quantized,
@@ -79,7 +81,7 @@ def test_quantized_batch_trains_like_the_raw_batch():
     q = next(iterate_quantized(files[0], B))
     la, ta, _ = process_minibatch(model, raw, FakeTimer(), 'cuda', True, ev, [0.5, 1, 1])
     lb, tb, _ = process_minibatch(model, q, FakeTimer(), 'cuda', False, ev, [0.5, 1, 1])
-    assert float(la) == float(lb)
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
     lb.backward()
     g = [p.grad for p in model.predictor.parameters()]
     assert all(x is not None and bool(torch.isfinite(x).all()) for x in g)
