@@ -139,12 +139,12 @@ def executed_flops(desc, kind):
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC
-    passes (profiles/round1/f_traffic_pmc.csv, made by tools/pmc_traffic.py: FETCH_SIZE x2 for the gfx950
+    passes (profiles/round1/h_traffic_pmc.csv, made by tools/pmc_traffic.py: FETCH_SIZE x2 for the gfx950
     under-count + WRITE_SIZE, separate --pmc runs of tools/conv_bench.py on the
     same workload).  PMC cannot be collected from inside this process, so this
     is a recorded measurement, not a live one; None if the file is absent."""
     import csv
-    path = ROOT / 'profiles' / 'round1' / 'f_traffic_pmc.csv'
+    path = ROOT / 'profiles' / 'round1' / 'h_traffic_pmc.csv'
     if not path.exists():
         return None
     prefix = kernel.split('>')[0]          # e.g. gconv2_kernel<2,2,1,1
@@ -227,7 +227,7 @@ def measure_roofline(h, step_ms, steps=3):
             'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(fl / sec / 1e12 / peak, 4),
             'traffic': pmc_traffic(dom),
-            'traffic_source': 'profiles/round1/f_traffic_pmc.csv (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950; bytes/launch)',
+            'traffic_source': 'profiles/round1/h_traffic_pmc.csv (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950; bytes/launch)',
             'avg_launch_us': round(sec / n * 1e6, 2),
             # the dominant kernel with the second backward stream switched off
             # (no other kernel on the GPU): same launches, same inputs
