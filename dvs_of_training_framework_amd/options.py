@@ -124,6 +124,11 @@ def add_train_arguments(parser):           # utils/options.py:204-302
     parser.add_argument('--skip-validation', dest='skip_validation',
                         action='store_true')
     # --- additions of this build
+    parser.add_argument('--compute-dtype', dest='compute_dtype', default='f32',
+                        choices=['f32', 'bf16x3', 'bf16'],
+                        help='matrix-core operand type of the conv stack: exact f32, '
+                             'bf16 hi+lo split (three products, ~f32 accuracy) or bf16; '
+                             'storage and accumulation are f32 in every mode')
     parser.add_argument('--synthetic', action='store_true',
                         help='train on seeded synthetic batches (no dataset)')
     parser.add_argument('--synthetic-events', dest='synthetic_events',
@@ -161,4 +166,8 @@ def options2dataset_kwargs(parameters):    # utils/options.py:332-338
 def options2model_kwargs(parameters):      # utils/options.py:341-347
     kwargs = options2dataset_kwargs(parameters)
     kwargs['activation'] = Mish() if parameters.mish else nn.ReLU()
+    # MI355X build only; models without this ctor argument never see it
+    # (model.init_model filters by signature, utils/model.py:10-23)
+    if getattr(parameters, 'compute_dtype', 'f32') != 'f32':
+        kwargs['compute_dtype'] = parameters.compute_dtype
     return kwargs
