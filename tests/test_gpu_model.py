@@ -356,3 +356,33 @@ def test_optimizer_fused_into_backward_is_the_same_update(opt_name):
     a, b = run(False), run(True)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('B,C,H,W,n', [
+    (2, 9, 480, 640, 100000),      # BASELINE.json configs[3] shape (MVSEC-like)
+    (1, 12, 512, 512, 300000),     # configs[4] shape
+    (2, 5, 260, 346, 20000),       # DAVIS frame size of the reference fixtures (padded to 272x352)
+])
+def test_one_training_step_at_other_baseline_shapes(B, C, H, W, n):
+    """Whole step at the other configured shapes: finite loss and gradients,
+    flows of the requested size, second run of the same step bit-identical
+    in the predictor (the voxeliser's float atomics aside: same grid reused)."""
+    from dvs_of_training_framework_amd import synthetic
+    from dvs_of_training_framework_amd.loss import init_losses
+    from dvs_of_training_framework_amd.net import Model
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch
+    torch.manual_seed(9)
+    model = Model('cuda', event_representation_depth=C)
+    model.train()
+    ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+    batch = synthetic.to_torch(synthetic.make_batch(17, B, H, W, n), 'cuda')
+    loss, terms, tags, info = process_minibatch(model, batch, FakeTimer(), 'cuda', True, ev,
+                                                [0.5, 1, 1], return_prediction=True)
+    assert [tuple(f.shape) for f in info['prediction']] == \
+        [(B, 2, H // s, W // s) for s in (8, 4, 2, 1)]
+    assert list(tags) == [f'{H // s}x{W // s}' for s in (8, 4, 2, 1)]
+    loss.backward()
+    assert np.isfinite(float(loss.detach()))
+    for p in model.predictor.parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all())
