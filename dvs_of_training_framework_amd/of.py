@@ -15,7 +15,13 @@ script_dir = osp.dirname(osp.realpath(__file__))
 class OpticalFlow:
     def __init__(self, imsize, model=osp.join(script_dir, 'data/model/model.pth'),
                  device=torch.device('cuda:0'), activation=nn.ReLU(),
-                 **model_kwargs):
+                 graph=False, **model_kwargs):
+        # graph=True: the whole inference (voxelise + weight forms + predictor)
+        # is captured once per (batch, event capacity) in a HIP graph and
+        # replayed; a batch-1 call is ~50 short launches that the host cannot
+        # enqueue as fast as the GPU runs them.  Events are padded to the
+        # capacity with x = y = -1 (ignored by the voxeliser).
+        self._use_graph, self._graphs = bool(graph), {}
         self._device = torch.device(device)
         self._net = Model(device=self._device, activation=activation,
                           **model_kwargs)
@@ -36,9 +42,54 @@ class OpticalFlow:
         """events: per sample (x, y, t, p) iterables, p in {-1, 1};
         start/stop: window bounds per sample."""
         with torch.no_grad():
-            flow, _, _ = self._net(*self._collate(events, start, stop),
-                                   self.imsize)
+            ev, ts, sidx = self._collate(events, start, stop)
+            if self._use_graph:
+                flow = self._replay(ev, ts, sidx, len(start))
+            else:
+                flow, _, _ = self._net(ev, ts, sidx, self.imsize)
             return self._postprocess(flow, return_all)
+
+    def _replay(self, ev, ts, sidx, B):
+        n = ev['x'].numel()
+        g = self._graphs.get(B)
+        if g is None or n > g['cap']:
+            cap = max(4096, 1 << max(n - 1, 1).bit_length())
+            st = {k: torch.zeros(cap, dtype=v.dtype, device=self._device)
+                  for k, v in ev.items()}
+            g = dict(cap=cap, ev=st, ts=torch.zeros_like(ts),
+                     sidx=sidx.clone(), graph=None, flow=None)
+            self._graphs[B] = g
+        assert ts.numel() == g['ts'].numel()
+        if g.get('done') is not None:
+            g['done'].synchronize()       # the static inputs are free again
+        for k, v in ev.items():
+            g['ev'][k][:n].copy_(v)
+        g['ev']['x'][n:] = -1
+        g['ev']['y'][n:] = -1
+        g['ev']['sample_index'][n:] = 0
+        g['ts'].copy_(ts)
+        g['sidx'].copy_(sidx)
+        if g['graph'] is None:
+            # one validated eager call (host-side assertions, lazy inits), then
+            # capture without them
+            self._net.strict = True
+            self._net(g['ev'], g['ts'], g['sidx'], self.imsize, batch_size=B)
+            self._net.strict = False
+            torch.cuda.synchronize(self._device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g['flow'] = self._net(g['ev'], g['ts'], g['sidx'], self.imsize,
+                                      batch_size=B)[0]
+            g['graph'] = graph
+        # one replay in flight at a time: launching the graph again while the
+        # previous replay is still running faulted on ROCm 7.2 (write to a
+        # read-only page); __call__ copies the result to the host anyway
+        if g.get('done') is not None:
+            g['done'].synchronize()
+        g['graph'].replay()
+        g['done'] = torch.cuda.Event()
+        g['done'].record()
+        return g['flow']
 
     def _collate(self, events, start, stop):
         """Stack the samples into one event dict with a sample index

@@ -386,3 +386,28 @@ def test_one_training_step_at_other_baseline_shapes(B, C, H, W, n):
     assert np.isfinite(float(loss.detach()))
     for p in model.predictor.parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all())
+
+
+def test_optical_flow_graph_replay_matches_eager_calls():
+    """OpticalFlow(graph=True): the captured HIP graph (voxelise + weight
+    forms + predictor) reproduces the eager call, also when a later call has
+    fewer events than the captured capacity (padding with x = y = -1)."""
+    from dvs_of_training_framework_amd.of import OpticalFlow
+    H = W = 64
+    rng = np.random.default_rng(3)
+
+    def events(n):
+        return [(rng.integers(0, W, n), rng.integers(0, H, n),
+                 np.sort(rng.random(n) * 0.04), rng.integers(0, 2, n) * 2 - 1)
+                for _ in range(2)]
+    torch.manual_seed(4)
+    eager = OpticalFlow((H, W), model=None, event_representation_depth=5)
+    graph = OpticalFlow((H, W), model=None, graph=True, event_representation_depth=5)
+    graph.load_state_dict(eager._net.state_dict())
+    for n in (6000, 6000, 2500, 5999):
+        ev = events(n)
+        a = eager(ev, [0.0, 0.0], [0.04, 0.04])
+        b = graph(ev, [0.0, 0.0], [0.04, 0.04])
+        assert a.shape == b.shape == (2, H, W, 2)
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())
+    assert len(graph._graphs) == 1 and graph._graphs[2]['cap'] == 16384
