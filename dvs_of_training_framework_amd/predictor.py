@@ -193,9 +193,6 @@ class _PredictorFn(torch.autograd.Function):
         keep = []
 
         def wgrad(desc, gz, gw, gb, unit):
-            if os.environ.get('DVSOF_DBG_SKIP_WGRAD'):
-                finish(unit)
-                return
             if side is None:
                 C.conv_wgrad(desc, gz, gw, gb)
                 finish(unit)
@@ -279,7 +276,7 @@ class _PredictorFn(torch.autograd.Function):
                                actsrc=asrc(below))], act)
             gz = g_prev
         for desc, g, gw, gb, unit in deferred:
-            if side is None or os.environ.get('DVSOF_ENC_WGRAD_SIDE'):
+            if side is None:
                 wgrad(desc, g, gw, gb, unit)
             else:
                 C.conv_wgrad(desc, g, gw, gb)
