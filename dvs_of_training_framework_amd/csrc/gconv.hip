@@ -269,30 +269,20 @@ int launch(const GConvParams &P, hipStream_t st)
 
 }  // namespace
 
-// largest tile that still gives every CU work (256 CUs)
+// MFMA tile of the forward / data-gradient kernels: 1 = 128x128, 2 = 128x64,
+// 3 = 64x64, 4 = 256x32, 5 = 128x32 (rows x output channels).
+// Chosen by measurement, not by a cost model: with every tile forced in turn
+// (DVSOF_GCONV_TILE, tools/tile_sweep.sh) over the EV-FlowNet layers at batch
+// 1, 8 and 32, 64x64 is the fastest or within 1 % of it on every layer with
+// more than 32 output channels -- the larger tiles reuse operands better but
+// run fewer workgroups per CU, and the barrier-synchronised K loop wants the
+// extra workgroups to cover its stalls -- and 128x32 wins for the 32-channel
+// decoder stage (+7 % over 256x32; 64x64 would pad N to 64).  At batch 1 the
+// 64x64 tile is 2.5-3.5x faster than 128x128 on the 16x16 and 32x32 stages.
 int gconv_pick_tile(long long m, long long n)
 {
-    // candidates: id, BM, BN.  Cost = padded MACs, with a penalty for grids
-    // that cannot fill 256 CUs and a mild preference for larger tiles.
-    static const int cand[5][3] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {4, 256, 32}, {5, 128, 32}};
-    // base efficiency of each tile shape (operand reuse per MFMA)
-    static const double eff[5] = {1.0, 0.95, 0.85, 0.85, 0.75};
-    int best = 3;
-    double best_cost = 1e300;
-    for (int i = 0; i < 5; ++i) {
-        const int bm = cand[i][1], bn = cand[i][2];
-        const long long tm = (m + bm - 1) / bm, tn = (n + bn - 1) / bn;
-        const double blocks = (double)(tm * tn);
-        double cost = (double)tm * bm * (double)tn * bn / eff[i];
-        // one workgroup per CU cannot hide load latency: want >= 2 per CU
-        const double bpc = blocks / 256.0;
-        if (bpc < 2.0) cost *= 2.0 / (bpc < 0.25 ? 0.25 : bpc);
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = cand[i][0];
-        }
-    }
-    return best;
+    (void)m;
+    return n <= 32 ? 5 : 3;
 }
 
 // ---- trailing "flat" output channel ranges (the 2-channel flow gradient of a
@@ -498,7 +488,9 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
             return DVSOF_OK;
         }
     }
-    const int tile = tile_hint > 0 ? tile_hint : gconv_pick_tile((long long)P.M * P.nph, P.N);
+    static const int tile_env = getenv("DVSOF_GCONV_TILE") ? atoi(getenv("DVSOF_GCONV_TILE")) : 0;   // tuning sweeps
+    const int tile = tile_hint > 0 ? tile_hint : tile_env > 0 ? tile_env
+                                                              : gconv_pick_tile((long long)P.M * P.nph, P.N);
     {   // v2 (LDS-DMA ring, VALU-free main loop) when the shape allows it
         static const bool force_v1 = getenv("DVSOF_GCONV_V1") != nullptr;
         long long src_bytes = 0;
