@@ -656,7 +656,16 @@ int pick_tile_and_splits(const WGradParams &P, int *S_out)
 int wgrad_splits(const WGradParams &P0, int *tile_out)
 {
     int S = 1;
-    const int tile = pick_tile_and_splits(P0, &S);
+    int tile = pick_tile_and_splits(P0, &S);
+    // tuning sweeps (tools/wgrad_sweep.sh): force the tile and / or the K splits
+    static const int tile_env = getenv("DVSOF_WGRAD_TILE") ? atoi(getenv("DVSOF_WGRAD_TILE")) : 0;
+    static const int s_env = getenv("DVSOF_WGRAD_SPLITS") ? atoi(getenv("DVSOF_WGRAD_SPLITS")) : 0;
+    if (tile_env >= 1 && tile_env <= 5) tile = tile_env;
+    if (s_env >= 1) {
+        const long long cap = (P0.M + BK - 1) / BK;
+        S = s_env > 64 ? 64 : s_env;
+        if (S > cap) S = (int)cap;
+    }
     if (tile_out) *tile_out = tile;
     return S;
 }
