@@ -23,7 +23,8 @@ class ConvDesc(ctypes.Structure):
     """dvsof_conv_desc_t"""
     _fields_ = [('src', Src * 3), ('nsrc', _i), ('B', _i), ('H', _i),
                 ('W', _i), ('upsample', _i), ('ksize', _i), ('stride', _i),
-                ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i)]
+                ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i),
+                ('scratch', _vp), ('scratch_bytes', _sz)]
 
 
 class GradDst(ctypes.Structure):
@@ -53,6 +54,7 @@ _lib.register('dvsof_conv2d_kernel_generation', _i, [_P(ConvDesc), _i])
 _lib.register('dvsof_conv2d_fwd_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_dgrad_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])
+_lib.register('dvsof_conv2d_scratch_bytes', _sz, [_P(ConvDesc)])
 
 
 MFMA_F32, MFMA_BF16, MFMA_BF16X3 = 0, 1, 2
@@ -81,8 +83,17 @@ def out_size(desc):
     return ho, wo
 
 
-def _dev(desc_or_tensor):
-    return desc_or_tensor.device
+def _scratch(desc, device):
+    """Attach the scratch a Winograd-evaluated layer needs for this call
+    (dvsof_conv2d_scratch_bytes; stream-ordered reuse by torch's allocator).
+    -> the tensor, to be kept alive until the call is enqueued."""
+    n = _lib.lib().dvsof_conv2d_scratch_bytes(ctypes.byref(desc))
+    if n == 0:
+        desc.scratch, desc.scratch_bytes = None, 0
+        return None
+    t = torch.empty(n // 4, dtype=torch.float32, device=device)
+    desc.scratch, desc.scratch_bytes = t.data_ptr(), n
+    return t
 
 
 def conv_fwd(desc, weight, bias, device, residual=None, want_z=False):
@@ -91,6 +102,7 @@ def conv_fwd(desc, weight, bias, device, residual=None, want_z=False):
     y = torch.empty(desc.B, ho, wo, desc.Cout, dtype=torch.float32,
                     device=device)
     z = torch.empty_like(y) if want_z else None
+    ws = _scratch(desc, device)     # noqa: F841  (alive across the call)
     _lib.check(_lib.lib().dvsof_conv2d_fwd(
         ctypes.byref(desc), weight.data_ptr(), _lib.ptr(bias),
         _lib.ptr(residual), y.data_ptr(), _lib.ptr(z), _lib.stream()),
@@ -144,6 +156,7 @@ def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE):
         arr[i].addend = _lib.ptr(d.get('addend'))
         arr[i].addend2 = _lib.ptr(d.get('addend2'))
         arr[i].actsrc = _lib.ptr(d.get('actsrc'))
+    ws = _scratch(desc, gout.device)     # noqa: F841
     _lib.check(_lib.lib().dvsof_conv2d_dgrad(
         ctypes.byref(desc), weight_t.data_ptr(), gout.data_ptr(), arr,
         bwd_act, _lib.stream()), 'dvsof_conv2d_dgrad')

@@ -11,6 +11,11 @@ size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat);
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias);
 int gconv_pick_tile(long long m, long long n);
 int wgrad_splits(const WGradParams &P0, int *tile_out);
+bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int H, int W, int ksize, int stride,
+                         int pad, int upsample, int mfma);
+size_t wino_scratch_floats(int B, int H, int W, int C, int N);
+int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, hipStream_t st);
+int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st);
 
 namespace {
 
@@ -59,6 +64,14 @@ bool desc_ok(const dvsof_conv_desc_t *d, int &Ctot, int &Ho, int &Wo)
 bool is_subpixel(const dvsof_conv_desc_t *d)
 {   // up2 + 3x3/pad1/stride1 == four 2x2 phase convolutions on the low-res input
     return d->upsample && d->ksize == 3 && d->pad == 1 && d->stride == 1;
+}
+
+// wide 3x3 stride-1 layer evaluated as Winograd F(2x2,3x3) (winograd.hip)
+bool is_wino(const dvsof_conv_desc_t *d)
+{
+    return d->nsrc == 1 &&
+           wino_eligible_shape(d->nsrc, d->src[0].layout == DVSOF_NHWC, d->src[0].C, d->Cout, d->H,
+                               d->W, d->ksize, d->stride, d->pad, d->upsample, d->mfma);
 }
 
 // Wf[ph][co][a][b][ci] = sum_{ky in S(py,a)} sum_{kx in S(px,b)} W[co][ky][kx][ci]
@@ -452,6 +465,8 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
         P.dst[0].ph_y = Wo * d->Cout;
         P.dst[0].ph_x = d->Cout;
     }
+    if (is_wino(d))   // `weight` is the prepared U[16][Cout][Ctot]
+        return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
     return gconv_launch(P, 0, as_stream(stream));
 }
 
@@ -540,7 +555,16 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         P.quad = 0;
     }
     P.M = d->B * P.Ho * P.Wo;
+    if (is_wino(d))   // weight_t is the prepared U'[16][Ctot][Cout]
+        return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
     return gconv_launch(P, 0, as_stream(stream));
+}
+
+size_t dvsof_conv2d_scratch_bytes(const dvsof_conv_desc_t *d)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo) || !is_wino(d)) return 0;
+    return wino_scratch_floats(d->B, d->H, d->W, Ctot, d->Cout) * sizeof(float);
 }
 
 size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
@@ -574,14 +598,14 @@ size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
-    return (size_t)d->Cout * Ctot * (is_subpixel(d) ? 16 : d->ksize * d->ksize);
+    return (size_t)d->Cout * Ctot * ((is_subpixel(d) || is_wino(d)) ? 16 : d->ksize * d->ksize);
 }
 
 size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
-    if (is_subpixel(d) || is_stride2_phased(d)) return (size_t)d->Cout * Ctot * 16;
+    if (is_subpixel(d) || is_stride2_phased(d) || is_wino(d)) return (size_t)d->Cout * Ctot * 16;
     return (size_t)d->Cout * Ctot * d->ksize * d->ksize;
 }
 
@@ -609,6 +633,10 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
             DVSOF_LAUNCH_CHECK();
         }
         return DVSOF_OK;
+    }
+    if (is_wino(d)) {   // weight == NULL: w_fwd already holds U, only U' is derived
+        if (!w_fwd || (!weight && !w_dgrad)) return DVSOF_EINVAL;
+        return wino_prepare(weight, w_fwd, w_dgrad, d->Cout, Ctot, st);
     }
     if (!weight) return DVSOF_EINVAL;
     if (is_stride2_phased(d) && w_dgrad) {

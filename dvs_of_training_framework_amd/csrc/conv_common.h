@@ -54,6 +54,8 @@ struct GConvParams {
     int nph;            // 1, or 4 sub-pixel output phases (blockIdx.z)
     int ph_pad;         // pad of phase (py,px) = pad - py*ph_pad / pad - px*ph_pad
     long long w_phase_stride;  // elements between the weights of two phases
+    long long src_ph_stride;   // elements between the source planes of two phases (0: phases share
+                               // the sources; winograd.hip runs its 16 component GEMMs as phases)
     int N, Cin_tot, M;
     int quad;           // rows ordered (b,y,x,dy,dx); epilogue sums the 2x2 quad
     int act;            // forward activation (ACT_*), applied after bias+addend

@@ -315,8 +315,9 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         bool new_tap = true;
         long long a_sb = P.src[it_s].sb;
         int a_sy = P.src[it_s].sy, a_sx = P.src[it_s].sx;
+        const size_t a_ph = (size_t)ph * P.src_ph_stride;
         __amdgpu_buffer_rsrc_t ares =
-            __builtin_amdgcn_make_buffer_rsrc((void *)P.src[it_s].p, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *)(P.src[it_s].p + a_ph), 0, 0x7fffffff, 0x00020000);
 
         auto issue_impl = [&](auto probec, int stage_idx) {
             constexpr bool PROBE = decltype(probec)::value;   // timing probes compiled in?
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                             a_sb = P.src[it_s].sb;
                             a_sy = P.src[it_s].sy;
                             a_sx = P.src[it_s].sx;
-                            ares = __builtin_amdgcn_make_buffer_rsrc((void *)P.src[it_s].p, 0,
+                            ares = __builtin_amdgcn_make_buffer_rsrc((void *)(P.src[it_s].p + a_ph), 0,
                                                                      0x7fffffff, 0x00020000);
                         }
                     }

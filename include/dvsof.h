@@ -264,7 +264,25 @@ typedef struct {
                  2: operands split into bf16 hi + lo, products hi*hi + hi*lo +
                  lo*hi (the dropped lo*lo term is 2^-16 relative).
                  Every tensor stays f32 in memory in all modes. */
+    void *scratch;        /* device scratch for layers that run as Winograd */
+    size_t scratch_bytes; /* F(2x2,3x3) (dvsof_conv2d_scratch_bytes > 0); read by
+                             dvsof_conv2d_fwd / _dgrad only, which return
+                             DVSOF_ENOSPACE when it is missing or too small */
 } dvsof_conv_desc_t;
+
+/*
+ * Bytes of scratch dvsof_conv2d_fwd / dvsof_conv2d_dgrad need for this layer:
+ * non-zero for the wide 3x3 stride-1 layers (one NHWC source, channel counts
+ * multiples of 64 and >= 256, even H and W, mfma != 1), which are evaluated as
+ * Winograd F(2x2,3x3): input transform, 16 component GEMMs on the matrix
+ * cores, output transform with the fused epilogue -- 2.25x fewer multiply-adds,
+ * same result up to fp32 rounding of the transforms (~1e-6 relative).  Their
+ * prepared weights are U[16][Cout][Ctot] forward and U'[16][Ctot][Cout]
+ * backward (dvsof_conv2d_prepare; as for a sub-pixel layer, weight == NULL
+ * derives U' from an existing U).  The scratch holds the transformed input
+ * and the component products; it is only used during the call.
+ */
+size_t dvsof_conv2d_scratch_bytes(const dvsof_conv_desc_t *desc);
 
 /*
  * Prepared weights.  An upsampled 3x3/pad-1 layer is evaluated as four 2x2

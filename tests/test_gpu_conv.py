@@ -41,6 +41,9 @@ CASES = [
     dict(B=2, H=9, W=7, src=[(20, 'nhwc')], Cout=48, stride=1, k=5, pad=2),
     dict(B=2, H=16, W=16, src=[(64, 'nhwc'), (64, 'nhwc'), (2, 'nchw')], Cout=32,
          up=True, act='mish'),
+    # wide 3x3 stride-1 layers: Winograd F(2x2,3x3) forward and data gradient
+    dict(B=2, H=8, W=6, src=[(256, 'nhwc')], Cout=320, stride=1, residual=True, wino=True),
+    dict(B=1, H=4, W=4, src=[(320, 'nhwc')], Cout=256, stride=1, act='mish', wino=True),
 ]
 
 
@@ -102,6 +105,10 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     ho, wo = C.out_size(desc)
     res = torch.randn(case['B'], case['Cout'], ho, wo) if case.get('residual') else None
     y_ref, z_ref = torch_fwd(xs, w, b, o, act, C, res)
+    import ctypes
+    nscratch = C._lib.lib().dvsof_conv2d_scratch_bytes(ctypes.byref(desc))
+    # the Winograd path is the one under test (bf16-rounded operands stay direct)
+    assert (nscratch > 0) == (bool(case.get('wino')) and mfma != 'bf16')
     w_dev = wphys(w.detach())
     w_fwd, wt = C.prepare(desc, w_dev, True)     # sub-pixel forms for up-layers
     y, z = C.conv_fwd(desc, w_fwd, b.cuda(), 'cuda',
@@ -129,9 +136,12 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     close(db, b.grad)
 
 
-def test_dgrad_epilogue_addends_and_act():
+@pytest.mark.parametrize('case', [
+    dict(B=2, H=8, W=8, src=[(32, 'nhwc')], Cout=64, stride=2),
+    dict(B=2, H=8, W=8, src=[(256, 'nhwc')], Cout=256, stride=1),     # Winograd
+])
+def test_dgrad_epilogue_addends_and_act(case):
     from dvs_of_training_framework_amd import conv as C
-    case = dict(B=2, H=8, W=8, src=[(32, 'nhwc')], Cout=64, stride=2)
     C, xs, w, b, desc, act, o = build(case, seed=3)
     x = xs[0].requires_grad_(True)
     _, z_ref = torch_fwd([x], w, b, o, act, C)
@@ -140,7 +150,7 @@ def test_dgrad_epilogue_addends_and_act():
     a1, a2 = torch.randn(x.shape), torch.randn(x.shape)
     ysrc = torch.randn(x.shape)
     want = (x.grad + a1 + a2) * (ysrc > 0).float()
-    buf = torch.empty(2, 8, 8, 32, device='cuda')
+    buf = torch.empty(2, 8, 8, case['src'][0][0], device='cuda')
     _, wt = C.prepare(desc, wphys(w), True)
     C.conv_dgrad(desc, wt, nhwc(gz), [dict(p=buf, addend=nhwc(a1), addend2=nhwc(a2),
                                            actsrc=nhwc(ysrc))], C.ACT_RELU)
