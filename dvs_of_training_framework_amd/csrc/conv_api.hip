@@ -16,6 +16,9 @@ bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int H, int W, 
 size_t wino_scratch_floats(int B, int H, int W, int C, int N);
 int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, hipStream_t st);
 int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st);
+size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N);
+int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
+                      int C, int N, int mfma_bf16, float *ws, size_t ws_floats, hipStream_t st);
 
 namespace {
 
@@ -72,6 +75,14 @@ bool is_wino(const dvsof_conv_desc_t *d)
     return d->nsrc == 1 &&
            wino_eligible_shape(d->nsrc, d->src[0].layout == DVSOF_NHWC, d->src[0].C, d->Cout, d->H,
                                d->W, d->ksize, d->stride, d->pad, d->upsample, d->mfma);
+}
+
+// ... and its weight gradient too: the tile count is the K dimension of the
+// K-major kernel, which loads whole 16-element groups
+bool is_wino_wgrad(const dvsof_conv_desc_t *d)
+{
+    static const bool off = getenv("DVSOF_NO_WINOGRAD_WGRAD") != nullptr;
+    return !off && is_wino(d) && (d->B * (d->H / 2) * (d->W / 2)) % BK == 0;
 }
 
 // Wf[ph][co][a][b][ci] = sum_{ky in S(py,a)} sum_{kx in S(px,b)} W[co][ky][kx][ci]
@@ -358,6 +369,7 @@ void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParam
     P.g_sy = Wo * d->Cout;
     P.g_sx = d->Cout;
     P.g_py = P.g_px = 0;
+    P.src_ph_stride = 0;
     if (is_subpixel(d)) {   // four 2x2 phase problems over the low-res pixels
         P.Hv = d->H;
         P.Wv = d->W;
@@ -571,6 +583,7 @@ size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
+    if (is_wino_wgrad(d)) return wino_wgrad_workspace_floats(d->B, d->H, d->W, Ctot, d->Cout) * sizeof(float) + 16;
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
     FlatWG F[3];
@@ -583,6 +596,11 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo) || !gout || !dweight) return DVSOF_EINVAL;
+    if (is_wino_wgrad(d))
+        return wino_wgrad_launch(make_src(d->src[0].p, d->src[0].C, d->src[0].layout, d->H, d->W), gout,
+                                 dweight, dbias, d->B, d->H, d->W, Ctot, d->Cout,
+                                 d->mfma == 2 ? 2 : 0, (float *)ws, ws_bytes / sizeof(float),
+                                 as_stream(stream));
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
     P.gout = gout;

@@ -86,6 +86,7 @@ struct WGradParams {
     int g_py, g_px;       // gout offsets of output phase (py, px)
     int nph, ph_pad, S;   // phases (1|4), pad shift per phase, K splits
     int mfma_bf16;        // as in GConvParams
+    long long src_ph_stride;   // elements between the source planes of two phases (winograd.hip)
 };
 
 // Weight gradient of one flat concat member on the VALU (wgrad.hip), in the

@@ -545,7 +545,8 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
     {   // larger stages cost occupancy: only when the grid is <= 2 workgroups per CU anyway
         const long long bm = 128 >> (tile == 3), bn = 64;
         const long long blocks = ((P.M + bm - 1) / bm) * ((P.N + bn - 1) / bn) * P.nph;
-        if (blocks > 2 * 256) k32 = false;
+        static const long long k32_blocks = getenv("DVSOF_GCONV_K32_BLOCKS") ? atoll(getenv("DVSOF_GCONV_K32_BLOCKS")) : 2 * 256;
+        if (blocks > k32_blocks) k32 = false;
     }
     int ksub = k32 ? 2 : 1;
     // one workgroup per CU (8-wave form): K depth 64 per barrier -- both waves of

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
     const __amdgpu_buffer_rsrc_t gres =
         __builtin_amdgcn_make_buffer_rsrc((void *)P.gout, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(S.p - ((long long)pad_y * s_sy + (long long)pad_x * s_sx)), 0, 0x7fffffff,
+        (void *)(S.p + (long long)ph * P.src_ph_stride - ((long long)pad_y * s_sy + (long long)pad_x * s_sx)), 0, 0x7fffffff,
         0x00020000);
     const long long g_ph = (long long)phy * P.g_py + (long long)phx * P.g_px;
 

@@ -19,6 +19,18 @@
 // by a transpose plus the component permutation (3,1,2,0) x (3,1,2,0): the
 // 180-degree rotated kernel g' satisfies G g' G^T = P (G g G^T) P.
 //
+// Weight gradient: dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G, again 16
+// GEMMs, now contracting over the tiles (the K-major LDS-DMA kernel of
+// wgrad2.hip run as a 1x1-conv weight gradient with 16 phases):
+//
+//   wino_input_kernel    V[16][T][C]   = B^T d B
+//   wino_gout_kernel     Z[16][T][N]   = A dY A^T
+//   wgrad2_kernel        dU[16][S][N][C] = sum_t Z[g][t][n] V[g][t][c]   (S K-splits)
+//   wino_dw_kernel       dW[n][3][3][c] = G^T (sum_S dU) G;  dbias = sum_S colsum(Z[5])
+//
+// (component 5 = (1,1) of A dY A^T is the plain 2x2 sum of dY, so the bias
+// gradient is the column sum wgrad2 already takes of its A operand.)
+//
 // V and Mb live in a caller-provided scratch (dvsof_conv_desc_t.scratch); at
 // the residual layers' size (T = 512 tiles, 512 channels) they are 16 MiB each
 // and stay in the 256 MiB memory-side cache between the three launches.
@@ -28,6 +40,8 @@
 
 bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_bytes);
 int gconv2_launch(const GConvParams &P, int tile, hipStream_t st);
+bool wgrad2_eligible(const WGradParams &P);
+int wgrad2_launch(const WGradParams &P, int tile, int ntiles, hipStream_t st);
 
 namespace {
 
@@ -207,6 +221,85 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     }
 }
 
+// Z[g][t][n] = (A dY A^T)[g], dY = the tile's 2x2 output gradients (dense NHWC gout)
+__global__ __launch_bounds__(256) void wino_gout_kernel(const float *__restrict__ gout,
+                                                        const WinoGeom G, int N, float *__restrict__ Z)
+{
+    const int n4n = N >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)G.T * n4n) return;
+    const int t = (int)(idx / n4n), n = (int)(idx - (long long)t * n4n) * 4;
+    const int tx = t % G.Tw, r = t / G.Tw, ty = r % G.Th, b = r / G.Th;
+    const float *p = gout + (((size_t)b * G.H + 2 * ty) * G.W + 2 * tx) * N + n;
+    const f32x4 d00 = ld4(p), d01 = ld4(p + N), d10 = ld4(p + (size_t)G.W * N),
+                d11 = ld4(p + (size_t)G.W * N + N);
+    // rows of A: (1,0) (1,1) (1,-1) (0,-1)
+    f32x4 u[4][2];
+    u[0][0] = d00;
+    u[0][1] = d01;
+    u[1][0] = d00 + d10;
+    u[1][1] = d01 + d11;
+    u[2][0] = d00 - d10;
+    u[2][1] = d01 - d11;
+    u[3][0] = -d10;
+    u[3][1] = -d11;
+    const size_t plane = (size_t)G.T * N;
+    float *o = Z + (size_t)t * N + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        st4(o + (size_t)(4 * i) * plane, u[i][0]);
+        st4(o + (size_t)(4 * i + 1) * plane, u[i][0] + u[i][1]);
+        st4(o + (size_t)(4 * i + 2) * plane, u[i][0] - u[i][1]);
+        st4(o + (size_t)(4 * i + 3) * plane, -u[i][1]);
+    }
+}
+
+// dW[n][3][3][c] = G^T (sum over the S slabs of dU[g][s][n][c]) G; the trailing
+// workgroups add the S column-sum partials of component 5 into dbias.
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float *__restrict__ dU, int S, int N, int C,
+                                                      float *__restrict__ dW, int nb_main,
+                                                      const float *__restrict__ bias_part,
+                                                      float *__restrict__ dbias)
+{
+    if ((int)blockIdx.x >= nb_main) {
+        const int n = ((int)blockIdx.x - nb_main) * 256 + threadIdx.x;
+        if (n < N) {
+            float v = 0.f;
+            for (int s = 0; s < S; ++s) v += bias_part[(size_t)(5 * S + s) * N + n];
+            dbias[n] = v;
+        }
+        return;
+    }
+    const int c4n = C >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * c4n) return;
+    const int n = (int)(idx / c4n), c = (int)(idx - (long long)n * c4n) * 4;
+    const size_t plane = (size_t)N * C;
+    f32x4 m[4][4];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const float *p = dU + (size_t)g * S * plane + (size_t)n * C + c;
+        f32x4 v = ld4(p);
+        for (int s = 1; s < S; ++s) v += ld4(p + (size_t)s * plane);
+        m[g >> 2][g & 3] = v;
+    }
+    // rows of G^T: (1,.5,.5,0) (0,.5,-.5,0) (0,.5,.5,1)
+    f32x4 t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = m[0][j] + 0.5f * (m[1][j] + m[2][j]);
+        t[1][j] = 0.5f * (m[1][j] - m[2][j]);
+        t[2][j] = 0.5f * (m[1][j] + m[2][j]) + m[3][j];
+    }
+    float *o = dW + (size_t)n * 9 * C + c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        st4(o + (size_t)(3 * i) * C, t[i][0] + 0.5f * (t[i][1] + t[i][2]));
+        st4(o + (size_t)(3 * i + 1) * C, 0.5f * (t[i][1] - t[i][2]));
+        st4(o + (size_t)(3 * i + 2) * C, 0.5f * (t[i][1] + t[i][2]) + t[i][3]);
+    }
+}
+
 }  // namespace
 
 // A 3x3 / stride-1 / pad-1 problem over one dense NHWC source whose channel
@@ -292,13 +385,97 @@ int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hip
     if ((long long)16 * G.T * N * 4 >= 0x7fffffffLL || (long long)G.T * N >= 0x3fffffffLL ||
         !gconv2_eligible(Q, (long long)G.T * C * 4, (long long)16 * N * C * 4))
         return DVSOF_EINVAL;
-    const int rc = gconv2_launch(Q, 3, st);
+    static const int tile = getenv("DVSOF_WINO_TILE") ? atoi(getenv("DVSOF_WINO_TILE")) : 3;   // tuning
+    const int rc = gconv2_launch(Q, tile, st);
     if (rc) return rc;
 
     WinoOut O = {P.dst[0], P.bias, P.zout, P.act, P.bwd_act, N};
     const long long nout = (long long)G.T * (N / 4);
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st,
                        (const float *)Mb, O, G);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+// K splits of the weight-gradient GEMMs (K = tiles): enough workgroups for two
+// per CU with 64 x 128 tiles, at least 16 K steps each
+static int wino_wgrad_splits(int T, int N, int C)
+{
+    static const int s_env = getenv("DVSOF_WINO_WGRAD_SPLITS") ? atoi(getenv("DVSOF_WINO_WGRAD_SPLITS")) : 0;
+    int S = 1;
+    if (s_env > 0) S = s_env;
+    else {
+        const long long tiles = (long long)16 * ((N + 63) / 64) * ((C + 127) / 128);
+        while (tiles * S < 512 && T / (S * 2) >= 16 * BK) S *= 2;
+    }
+    while (S > 1 && (T + S - 1) / S < BK) --S;
+    return S;
+}
+
+size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N)
+{
+    const size_t T = (size_t)B * (H / 2) * (W / 2);
+    const int S = wino_wgrad_splits((int)T, N, C);
+    return 16 * T * ((size_t)C + N) + (size_t)16 * S * N * C + (size_t)16 * S * N;
+}
+
+int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
+                      int C, int N, int mfma_bf16, float *ws, size_t ws_floats, hipStream_t st)
+{
+    if (X.flat || X.sc != 1 || X.C != C) return DVSOF_EINVAL;
+    WinoGeom G = {B, H, W, H / 2, W / 2, B * (H / 2) * (W / 2)};
+    if (!ws || ws_floats < wino_wgrad_workspace_floats(B, H, W, C, N)) return DVSOF_ENOSPACE;
+    const int S = wino_wgrad_splits(G.T, N, C);
+    float *V = ws, *Z = V + (size_t)16 * G.T * C, *dU = Z + (size_t)16 * G.T * N;
+    float *bias_part = dU + (size_t)16 * S * N * C;
+
+    const long long nin = (long long)G.T * (C / 4), ng = (long long)G.T * (N / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, X, G, V);
+    DVSOF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wino_gout_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, gout, G, N, Z);
+    DVSOF_LAUNCH_CHECK();
+
+    WGradParams Q = {};
+    Q.nsrc = 1;
+    Q.src[0] = {V, (long long)G.T * C, G.T * C, C, 1, C, 0};
+    Q.src_ph_stride = (long long)G.T * C;
+    Q.gout = Z;
+    Q.dW = dU;
+    Q.dbias = dbias ? bias_part : nullptr;
+    Q.B = 1;
+    Q.Hv = Q.Ho = 1;
+    Q.Wv = Q.Wo = G.T;
+    Q.up = UP_NONE;
+    Q.stride = 1;
+    Q.pad = 0;
+    Q.ks = 1;
+    Q.Cout = N;
+    Q.Cin_tot = C;
+    Q.M = G.T;
+    Q.S = S;
+    Q.klen = (((G.T + S - 1) / S) + BK - 1) / BK * BK;
+    Q.g_sb = (long long)G.T * N;
+    Q.g_sy = G.T * N;
+    Q.g_sx = N;
+    Q.g_py = 2 * G.T * N;   // phase g = 2 phy + phx -> plane g of Z
+    Q.g_px = G.T * N;
+    Q.nph = 16;
+    Q.ph_pad = 0;
+    Q.mfma_bf16 = mfma_bf16;
+    static const int tile = getenv("DVSOF_WINO_WGRAD_TILE") ? atoi(getenv("DVSOF_WINO_WGRAD_TILE")) : 4;
+    const int bn = (tile == 2 || tile == 3) ? 64 : 128;
+    const int nt = (C + bn - 1) / bn;
+    Q.tile_begin[0] = 0;
+    Q.tile_begin[1] = nt;
+    if ((G.T % BK) || (long long)16 * G.T * (C > N ? C : N) * 4 >= 0x7fffffffLL || !wgrad2_eligible(Q))
+        return DVSOF_EINVAL;
+    const int rc = wgrad2_launch(Q, tile, nt, st);
+    if (rc) return rc;
+
+    const long long nw = (long long)N * (C / 4);
+    const int nb_main = (int)((nw + 255) / 256), nb_bias = dbias ? (N + 255) / 256 : 0;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)(nb_main + nb_bias)), dim3(256), 0, st,
+                       (const float *)dU, S, N, C, dW, nb_main, (const float *)bias_part, dbias);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

@@ -44,6 +44,8 @@ CASES = [
     # wide 3x3 stride-1 layers: Winograd F(2x2,3x3) forward and data gradient
     dict(B=2, H=8, W=6, src=[(256, 'nhwc')], Cout=320, stride=1, residual=True, wino=True),
     dict(B=1, H=4, W=4, src=[(320, 'nhwc')], Cout=256, stride=1, act='mish', wino=True),
+    # ... and weight gradient (tile count a multiple of 16)
+    dict(B=3, H=8, W=16, src=[(256, 'nhwc')], Cout=384, stride=1, wino=True),
 ]
 
 
