@@ -130,9 +130,13 @@ def prepare(desc, weight, want_dgrad, phase_weights=None):
         if want_dgrad else None
     make_fwd = not dg_only and nf != raw
     if make_fwd or want_dgrad:
+        # Winograd layer: both forms come from the raw weights
+        wino = lib.dvsof_conv2d_scratch_bytes(ctypes.byref(desc)) > 0
         # sub-pixel layer, dgrad only: weight = NULL, w_fwd = the phase kernels
-        wp = None if (dg_only and nf != raw) else weight.data_ptr()
+        wp = None if (dg_only and nf != raw and not wino) else weight.data_ptr()
         fp = w_fwd.data_ptr() if (nf != raw) else None
+        if wino and dg_only:
+            fp = None
         _lib.check(lib.dvsof_conv2d_prepare(
             ctypes.byref(desc), wp, fp, _lib.ptr(w_dg), _lib.stream()),
             'dvsof_conv2d_prepare')

@@ -13,10 +13,13 @@ int gconv_pick_tile(long long m, long long n);
 int wgrad_splits(const WGradParams &P0, int *tile_out);
 bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int H, int W, int ksize, int stride,
                          int pad, int upsample, int mfma);
-size_t wino_scratch_floats(int B, int H, int W, int C, int N);
-int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, hipStream_t st);
+int wino_components(int H, int W, int mfma);
+size_t wino_scratch_floats(int B, int H, int W, int C, int N, int mfma);
+int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int H, int W, int mfma,
+                 hipStream_t st);
 int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st);
-size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N);
+int wino_wgrad_tile(int B, int H, int W, int mfma);
+size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N, int mfma);
 int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
                       int C, int N, int mfma_bf16, float *ws, size_t ws_floats, hipStream_t st);
 
@@ -82,7 +85,7 @@ bool is_wino(const dvsof_conv_desc_t *d)
 bool is_wino_wgrad(const dvsof_conv_desc_t *d)
 {
     static const bool off = getenv("DVSOF_NO_WINOGRAD_WGRAD") != nullptr;
-    return !off && is_wino(d) && (d->B * (d->H / 2) * (d->W / 2)) % BK == 0;
+    return !off && is_wino(d) && wino_wgrad_tile(d->B, d->H, d->W, d->mfma == 2 ? 2 : 0) != 0;
 }
 
 // Wf[ph][co][a][b][ci] = sum_{ky in S(py,a)} sum_{kx in S(px,b)} W[co][ky][kx][ci]
@@ -576,14 +579,14 @@ size_t dvsof_conv2d_scratch_bytes(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo) || !is_wino(d)) return 0;
-    return wino_scratch_floats(d->B, d->H, d->W, Ctot, d->Cout) * sizeof(float);
+    return wino_scratch_floats(d->B, d->H, d->W, Ctot, d->Cout, d->mfma == 2 ? 2 : 0) * sizeof(float);
 }
 
 size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
-    if (is_wino_wgrad(d)) return wino_wgrad_workspace_floats(d->B, d->H, d->W, Ctot, d->Cout) * sizeof(float) + 16;
+    if (is_wino_wgrad(d)) return wino_wgrad_workspace_floats(d->B, d->H, d->W, Ctot, d->Cout, d->mfma == 2 ? 2 : 0) * sizeof(float) + 16;
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
     FlatWG F[3];
@@ -616,14 +619,16 @@ size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
-    return (size_t)d->Cout * Ctot * ((is_subpixel(d) || is_wino(d)) ? 16 : d->ksize * d->ksize);
+    if (is_wino(d)) return (size_t)d->Cout * Ctot * wino_components(d->H, d->W, d->mfma == 2 ? 2 : 0);
+    return (size_t)d->Cout * Ctot * (is_subpixel(d) ? 16 : d->ksize * d->ksize);
 }
 
 size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
-    if (is_subpixel(d) || is_stride2_phased(d) || is_wino(d)) return (size_t)d->Cout * Ctot * 16;
+    if (is_wino(d)) return (size_t)d->Cout * Ctot * wino_components(d->H, d->W, d->mfma == 2 ? 2 : 0);
+    if (is_subpixel(d) || is_stride2_phased(d)) return (size_t)d->Cout * Ctot * 16;
     return (size_t)d->Cout * Ctot * d->ksize * d->ksize;
 }
 
@@ -652,9 +657,9 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
         }
         return DVSOF_OK;
     }
-    if (is_wino(d)) {   // weight == NULL: w_fwd already holds U, only U' is derived
-        if (!w_fwd || (!weight && !w_dgrad)) return DVSOF_EINVAL;
-        return wino_prepare(weight, w_fwd, w_dgrad, d->Cout, Ctot, st);
+    if (is_wino(d)) {   // either form (or both) from the raw weights
+        if (!weight || (!w_fwd && !w_dgrad)) return DVSOF_EINVAL;
+        return wino_prepare(weight, w_fwd, w_dgrad, d->Cout, Ctot, d->H, d->W, d->mfma == 2 ? 2 : 0, st);
     }
     if (!weight) return DVSOF_EINVAL;
     if (is_stride2_phased(d) && w_dgrad) {

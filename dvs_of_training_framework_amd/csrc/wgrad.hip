@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void subpixel_fold_kernel(const float *__restr
 // needs neither the sub-pixel phases nor the MFMA tiles (an MFMA column tile
 // for 8..45 columns would run the whole K loop at <10 % utilisation).
 // HBM-bound: reads gout once.  part[block][co][NCOL], then a fixed-order sum.
-constexpr int FLAT_BLOCKS = 512;
+constexpr int FLAT_BLOCKS = 512;    // most partial sums of a flat member (workspace bound)
 constexpr int FLAT_PIX = 64;   // pixels staged per round
 
 
@@ -513,6 +513,143 @@ __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *
     }
 }
 
+// The same gradient on the matrix cores, no LDS in the loop: for
+// v_mfma_f32_32x32x2_f32 the A operand of lane (i = lane & 31, k = lane >> 5) is
+// gout[pixel 2q + k][channel i] -- consecutive lanes read consecutive channels,
+// a coalesced global load straight into the operand register -- and the B
+// operand is the im2col value of column j = lane & 31 at pixel 2q + k, gathered
+// from the small flat tensor (cache resident).  The kernel streams gout once;
+// it is bound by that read (67 MB at the finest decoder stage), not by the
+// 64-cycle MFMA per pixel pair.  2 x UN pixel pairs are in flight per wave, 8
+// waves per workgroup (a one-wave-per-workgroup version with UN pairs in
+// flight was latency bound: 49 us at the finest decoder stage).
+// NCB = ceil(ncol / 32) column blocks, NRB = 32-channel row blocks per pass.
+template <int NCB, int NRB>
+__global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, float *__restrict__ part)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int UN = 8, NW = 8;
+    __shared__ float red[NRB * NCB * 16 * 64];
+    const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ncol = P.ncol, C = P.S.C;
+    // pixel pairs of this wave (contiguous range)
+    const long long npair = ((long long)P.M + 1) / 2;
+    const long long per = (npair + (long long)gridDim.x * NW - 1) / ((long long)gridDim.x * NW);
+    const long long q0 = ((long long)blockIdx.x * NW + wave) * per;
+    const long long q1 = q0 + per < npair ? q0 + per : npair;
+    // per-lane column constants
+    int cky[NCB], ckx[NCB];
+    long long ccoff[NCB];
+    bool cok[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int col = cb * 32 + li;
+        cok[cb] = col < ncol;
+        const int tap = cok[cb] ? col / C : 0, c = col - tap * C;
+        cky[cb] = tap / P.ks;
+        ckx[cb] = tap - cky[cb] * P.ks;
+        ccoff[cb] = (long long)c * P.S.sc;
+    }
+    const int nrb = P.Cout / 32;
+    for (int rb0 = 0; rb0 < nrb; rb0 += NRB) {
+        f32x16 acc[NRB][NCB];
+#pragma unroll
+        for (int a = 0; a < NRB; ++a)
+#pragma unroll
+            for (int b = 0; b < NCB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        // this lane's pixel (2q + lk) as (b, oy, ox), advanced by 2 per step
+        long long pix = 2 * q0 + lk, qn = q0;
+        int ox = 0, oy = 0, bb = 0;
+        if (q0 < q1) {
+            ox = (int)(pix % P.Wo);
+            const long long t = pix / P.Wo;
+            oy = (int)(t % P.Ho);
+            bb = (int)(t / P.Ho);
+        }
+        const float *gp = P.gout + (size_t)pix * P.Cout + rb0 * 32 + li;
+        // UN pixel pairs: gout values and im2col values of this lane
+        auto load_set = [&](float (&av)[UN][NRB], float (&bv)[UN][NCB]) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const bool pok = (qn + u < q1) && (pix < P.M);
+#pragma unroll
+                for (int a = 0; a < NRB; ++a) av[u][a] = (pok && rb0 + a < nrb) ? gp[a * 32] : 0.f;
+                const int Y0 = oy * P.stride - P.pad, X0 = ox * P.stride - P.pad;
+                const float *sb = P.S.p + (size_t)bb * P.S.sb;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const int Y = Y0 + cky[cb], X = X0 + ckx[cb];
+                    const bool ok = pok & cok[cb] & ((unsigned)Y < (unsigned)P.Hv) &
+                                    ((unsigned)X < (unsigned)P.Wv);
+                    const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
+                    bv[u][cb] = ok ? sb[(size_t)ys * P.S.sy + (size_t)xs * P.S.sx + ccoff[cb]] : 0.f;
+                }
+                pix += 2;
+                gp += 2 * (size_t)P.Cout;
+                ox += 2;
+                if (ox >= P.Wo) {
+                    ox -= P.Wo;
+                    if (++oy == P.Ho) {
+                        oy = 0;
+                        ++bb;
+                    }
+                }
+            }
+            qn += UN;
+        };
+        auto mfma_set = [&](const float (&av)[UN][NRB], const float (&bv)[UN][NCB]) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int a = 0; a < NRB; ++a)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        acc[a][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][cb], acc[a][cb], 0, 0, 0);
+        };
+        // two register sets: the loads of the next UN pairs are in flight while
+        // the MFMAs of the current ones run
+        float a0[UN][NRB], b0[UN][NCB], a1[UN][NRB], b1[UN][NCB];
+        if (q0 < q1) load_set(a0, b0);
+        for (long long q = q0; q < q1; q += 2 * UN) {
+            if (q + UN < q1) load_set(a1, b1);
+            mfma_set(a0, b0);
+            if (q + UN < q1) {
+                if (q + 2 * UN < q1) load_set(a0, b0);
+                mfma_set(a1, b1);
+            }
+        }
+        // the 8 waves add up in LDS in wave order (fixed order: reproducible);
+        // the last one writes the workgroup's partial sum.
+        // acc[reg] <-> channel (reg & 3) + 8 (reg >> 2) + 4 lk of the row block, column li
+        for (int w = 0; w < NW; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int a = 0; a < NRB; ++a)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float *slot = &red[((a * NCB + cb) * 16 + r) * 64 + lane];
+                            const float v = w == 0 ? acc[a][cb][r] : *slot + acc[a][cb][r];
+                            if (w < NW - 1) {
+                                *slot = v;
+                            } else {
+                                const int col = cb * 32 + li;
+                                const int co = (rb0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                                if (rb0 + a < nrb && col < ncol)
+                                    part[((size_t)blockIdx.x * P.Cout + co) * ncol + col] = v;
+                            }
+                        }
+            }
+            __syncthreads();
+        }
+    }
+#endif
+}
+
 // dW[co][tap][coff + c] = sum_blocks part[blk][co][tap*C + c]; one wave per
 // output, lanes stride over the workgroups, shuffle tree (fixed order)
 __global__ __launch_bounds__(256) void wgrad_flat_reduce_kernel(const float *__restrict__ part,
@@ -540,7 +677,30 @@ bool flat_ncol_ok(int ncol)
 int flat_launch(const FlatWG &F, float *part, float *dW, hipStream_t st)
 {
     const long long nbl = ((long long)F.M + FLAT_PIX - 1) / FLAT_PIX;
-    const int nb = (int)(nbl < FLAT_BLOCKS ? (nbl < 1 ? 1 : nbl) : FLAT_BLOCKS);
+    int nb = (int)(nbl < 512 ? (nbl < 1 ? 1 : nbl) : 512);   // VALU kernel: 64 pixels per round
+    static const bool no_mfma = getenv("DVSOF_WGRAD_FLAT_VALU") != nullptr;
+    const int ncb = (F.ncol + 31) / 32, nrb = F.Cout / 32;
+    // measured (batch 8): MFMA 33 vs VALU 46 us at M = 524288 / 18 columns, 39 vs 52 us at
+    // M = 131072 / 45 columns; a tie at M = 131072 / 18 columns; VALU wins below
+    static const bool force_mfma = getenv("DVSOF_WGRAD_FLAT_MFMA") != nullptr;
+    const bool big = F.M >= 262144 || (ncb == 2 && F.M >= 65536);
+    if (!no_mfma && (big || force_mfma) && (F.Cout % 32) == 0 && ncb <= 2 && F.Wo >= 2) {
+        // 8 waves per workgroup, >= 32 pixel pairs per wave, at most 512 partial sums
+        const long long npair = ((long long)F.M + 1) / 2;
+        long long nw = npair / (32 * 8);
+        nw = nw < 1 ? 1 : nw > 512 ? 512 : nw;
+        nb = (int)nw;
+        if (ncb == 1 && nrb >= 4)
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 4>), dim3(nb), dim3(512), 0, st, F, part);
+        else if (ncb == 1 && nrb >= 2)
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 2>), dim3(nb), dim3(512), 0, st, F, part);
+        else if (ncb == 1)
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 1>), dim3(nb), dim3(512), 0, st, F, part);
+        else if (nrb >= 2)
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<2, 2>), dim3(nb), dim3(512), 0, st, F, part);
+        else
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<2, 1>), dim3(nb), dim3(512), 0, st, F, part);
+    } else
     switch (F.ncol) {
     case 18: hipLaunchKernelGGL(wgrad_flat_kernel<18>, dim3(nb), dim3(256), 0, st, F, part); break;
     case 27: hipLaunchKernelGGL(wgrad_flat_kernel<27>, dim3(nb), dim3(256), 0, st, F, part); break;

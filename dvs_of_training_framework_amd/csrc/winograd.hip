@@ -1,41 +1,43 @@
-// Winograd F(2x2, 3x3) for the wide 3x3 / stride-1 layers (EV-FlowNet's 512-channel
-// residual blocks): 16 multiplies per 2x2 output tile and channel pair instead
-// of 36, i.e. 2.25x fewer matrix-core FLOPs than the direct implicit GEMM.
+// Winograd convolution for the wide 3x3 / stride-1 layers (EV-FlowNet's 512-channel
+// residual blocks): F(4x4,3x3) when the image sides are multiples of 4 (36
+// multiplies per 4x4 output tile and channel pair instead of 144: 4x fewer
+// matrix-core FLOPs than the direct implicit GEMM), else F(2x2,3x3) (16 instead
+// of 36: 2.25x fewer).
 //
-//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        (Lavin & Gray 2016, F(2x2,3x3))
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        (Lavin & Gray 2016; points 0, +-1, +-2, inf)
 //
-// d = 4x4 input patch of one tile (stride 2 between tiles, zero padded),
-// g = 3x3 kernel.  The element-wise product summed over input channels is 16
-// independent GEMMs [tiles x Cin] x [Cin x Cout], one per Winograd component:
+// d = (m+2)x(m+2) input patch of one tile (stride m between tiles, zero padded),
+// g = 3x3 kernel, m = 2 | 4.  The element-wise product summed over input channels
+// is NG = (m+2)^2 independent GEMMs [tiles x Cin] x [Cin x Cout], one per component:
 //
-//   wino_input_kernel    V[16][T][C]  = B^T d B          (adds only)
-//   gconv2_kernel        Mb[16][T][N] = V[g] * U[g]^T    (the LDS-DMA MFMA kernel run
-//                                                         as a 1x1 conv with 16 "phases")
+//   wino_input_kernel    V[NG][T][C]  = B^T d B
+//   gconv2_kernel        Mb[NG][T][N] = V[g] * U[g]^T    (the LDS-DMA MFMA kernel run
+//                                                         as a 1x1 conv with NG "phases")
 //   wino_output_kernel   y = epilogue(A^T Mb A)          (bias, residual / gradient
 //                                                         addends, act' multiply, act)
 //
-// with U[16][N][C] = G g G^T made once per step by dvsof_conv2d_prepare
-// (wino_weight_kernel), and the data-gradient form U'[16][C][N] derived from U
-// by a transpose plus the component permutation (3,1,2,0) x (3,1,2,0): the
-// 180-degree rotated kernel g' satisfies G g' G^T = P (G g G^T) P.
+// with U[NG][N][C] = G g G^T made once per step by dvsof_conv2d_prepare
+// (wino_weight_kernel) and the data-gradient form U'[NG][C][N] = G g' G^T of the
+// 180-degree rotated, transposed kernel g'.
 //
-// Weight gradient: dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G, again 16
+// Weight gradient: dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G, again NG
 // GEMMs, now contracting over the tiles (the K-major LDS-DMA kernel of
-// wgrad2.hip run as a 1x1-conv weight gradient with 16 phases):
+// wgrad2.hip run as a 1x1-conv weight gradient with NG phases):
 //
-//   wino_input_kernel    V[16][T][C]   = B^T d B
-//   wino_gout_kernel     Z[16][T][N]   = A dY A^T
-//   wgrad2_kernel        dU[16][S][N][C] = sum_t Z[g][t][n] V[g][t][c]   (S K-splits)
-//   wino_dw_kernel       dW[n][3][3][c] = G^T (sum_S dU) G;  dbias = sum_S colsum(Z[5])
+//   wino_input_kernel    V[NG][T][C]   = B^T d B
+//   wino_gout_kernel     Z[NG][T][N]   = A dY A^T
+//   wgrad2_kernel        dU[NG][S][N][C] = sum_t Z[g][t][n] V[g][t][c]   (S K-splits)
+//   wino_dw_kernel       dW[n][3][3][c] = G^T (sum_S dU) G;  dbias = sum_S colsum(Z[(1,1)])
 //
-// (component 5 = (1,1) of A dY A^T is the plain 2x2 sum of dY, so the bias
-// gradient is the column sum wgrad2 already takes of its A operand.)
+// (row 1 of A is all ones, so component (1,1) of A dY A^T is the plain sum of the
+// tile's dY and the bias gradient is the column sum wgrad2 already takes of its A
+// operand.)
 //
-// V and Mb live in a caller-provided scratch (dvsof_conv_desc_t.scratch); at
-// the residual layers' size (T = 512 tiles, 512 channels) they are 16 MiB each
-// and stay in the 256 MiB memory-side cache between the three launches.
-// All transforms are exact up to f32 rounding of sums of at most four terms;
-// results agree with the direct kernel to ~1e-6 relative (tests/test_gpu_conv.py).
+// V, Mb, Z and dU live in caller-provided scratch (dvsof_conv_desc_t.scratch, the
+// weight-gradient workspace); at the residual layers' size they are 9-38 MiB
+// and stay in the 256 MiB memory-side cache between the launches.
+// Accuracy in f32 (tests/test_gpu_conv.py, tools/winograd_error.py): F(2x2) ~1e-6,
+// F(4x4) ~1e-5 of the output peak (direct kernel: ~3e-7); the parity bar is 1e-3.
 #include "conv_common.h"
 
 bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_bytes);
@@ -48,59 +50,149 @@ namespace {
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *(f32x4 *)p = v; }
 
-// U[g][n][c] from w[n][3][3][c]; one thread per (n, channel quad)
+// ---- the 1-D transforms (F = output tile side m; NA = m + 2 points)
+template <int F>
+struct Wino;
+
+template <>
+struct Wino<2> {
+    static constexpr int NA = 4;
+    // B^T: data
+    static __device__ __forceinline__ void bt(const f32x4 (&d)[4], f32x4 (&o)[4])
+    {
+        o[0] = d[0] - d[2];
+        o[1] = d[1] + d[2];
+        o[2] = d[2] - d[1];
+        o[3] = d[1] - d[3];
+    }
+    // G: kernel taps -> points
+    static __device__ __forceinline__ void g(const f32x4 (&w)[3], f32x4 (&o)[4])
+    {
+        o[0] = w[0];
+        o[1] = 0.5f * (w[0] + w[1] + w[2]);
+        o[2] = 0.5f * (w[0] - w[1] + w[2]);
+        o[3] = w[2];
+    }
+    // A^T: points -> outputs
+    static __device__ __forceinline__ void at(const f32x4 (&m)[4], f32x4 (&o)[2])
+    {
+        o[0] = m[0] + m[1] + m[2];
+        o[1] = m[1] - m[2] - m[3];
+    }
+    // A: output gradients -> points
+    static __device__ __forceinline__ void a(const f32x4 (&y)[2], f32x4 (&o)[4])
+    {
+        o[0] = y[0];
+        o[1] = y[0] + y[1];
+        o[2] = y[0] - y[1];
+        o[3] = -y[1];
+    }
+    // G^T: points -> kernel-tap gradients
+    static __device__ __forceinline__ void gt(const f32x4 (&m)[4], f32x4 (&o)[3])
+    {
+        o[0] = m[0] + 0.5f * (m[1] + m[2]);
+        o[1] = 0.5f * (m[1] - m[2]);
+        o[2] = 0.5f * (m[1] + m[2]) + m[3];
+    }
+};
+
+template <>
+struct Wino<4> {
+    static constexpr int NA = 6;
+    static __device__ __forceinline__ void bt(const f32x4 (&d)[6], f32x4 (&o)[6])
+    {
+        o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        o[1] = (d[3] + d[4]) - 4.f * (d[1] + d[2]);
+        o[2] = 4.f * (d[1] - d[2]) + (d[4] - d[3]);
+        o[3] = 2.f * (d[3] - d[1]) + (d[4] - d[2]);
+        o[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
+        o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+    static __device__ __forceinline__ void g(const f32x4 (&w)[3], f32x4 (&o)[6])
+    {
+        const f32x4 s = w[0] + w[2];
+        const f32x4 q = (1.f / 24.f) * w[0] + (1.f / 6.f) * w[2], h = (1.f / 12.f) * w[1];
+        o[0] = 0.25f * w[0];
+        o[1] = (-1.f / 6.f) * (s + w[1]);
+        o[2] = (-1.f / 6.f) * (s - w[1]);
+        o[3] = q + h;
+        o[4] = q - h;
+        o[5] = w[2];
+    }
+    static __device__ __forceinline__ void at(const f32x4 (&m)[6], f32x4 (&o)[4])
+    {
+        const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        o[0] = m[0] + s12 + s34;
+        o[1] = d12 + 2.f * d34;
+        o[2] = s12 + 4.f * s34;
+        o[3] = d12 + 8.f * d34 + m[5];
+    }
+    static __device__ __forceinline__ void a(const f32x4 (&y)[4], f32x4 (&o)[6])
+    {
+        const f32x4 e = y[0] + y[2], f = y[1] + y[3];
+        const f32x4 e4 = y[0] + 4.f * y[2], f4 = 2.f * y[1] + 8.f * y[3];
+        o[0] = y[0];
+        o[1] = e + f;
+        o[2] = e - f;
+        o[3] = e4 + f4;
+        o[4] = e4 - f4;
+        o[5] = y[3];
+    }
+    static __device__ __forceinline__ void gt(const f32x4 (&m)[6], f32x4 (&o)[3])
+    {
+        const f32x4 s12 = m[1] + m[2], s34 = m[3] + m[4];
+        o[0] = 0.25f * m[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        o[1] = (1.f / 6.f) * (m[2] - m[1]) + (1.f / 12.f) * (m[3] - m[4]);
+        o[2] = (1.f / 6.f) * (s34 - s12) + m[5];
+    }
+};
+
+// U[g][n][c] = (G w[n] G^T)[g] from w[n][3][3][c]; one thread per (n, channel quad).
+// TRANSPOSED: the data-gradient form Ut[g][c][n] of the 180-degree rotated kernel;
+// threads are then ordered n-fastest so that the (larger) write side is coalesced.
+template <int F, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ w,
                                                           float *__restrict__ U, int N, int C)
 {
+    constexpr int NA = Wino<F>::NA;
     const int c4n = C >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)N * c4n) return;
-    const int n = (int)(idx / c4n), c = (int)(idx - (long long)n * c4n) * 4;
-    f32x4 g[3][3], t[4][3];
+    int n, c;
+    if (TRANSPOSED) {
+        c = (int)(idx / N);
+        n = (int)(idx - (long long)c * N);
+        c *= 4;
+    } else {
+        n = (int)(idx / c4n);
+        c = (int)(idx - (long long)n * c4n) * 4;
+    }
+    f32x4 g[3][3], t[3][NA];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) g[i][j] = ld4(w + ((size_t)n * 9 + i * 3 + j) * C + c);
+        for (int j = 0; j < 3; ++j) {
+            const int tap = TRANSPOSED ? (2 - i) * 3 + (2 - j) : i * 3 + j;
+            g[i][j] = ld4(w + ((size_t)n * 9 + tap) * C + c);
+        }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {   // t = G g
-        t[0][j] = g[0][j];
-        t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
-        t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
-        t[3][j] = g[2][j];
-    }
+    for (int i = 0; i < 3; ++i) Wino<F>::g(g[i], t[i]);   // along kx
     const size_t plane = (size_t)N * C;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // U = t G^T
-        float *o = U + (size_t)(4 * i) * plane + (size_t)n * C + c;
-        st4(o, t[i][0]);
-        st4(o + plane, 0.5f * (t[i][0] + t[i][1] + t[i][2]));
-        st4(o + 2 * plane, 0.5f * (t[i][0] - t[i][1] + t[i][2]));
-        st4(o + 3 * plane, t[i][2]);
-    }
-}
-
-// Ut[g'][c][n] = U[perm(g')][n][c], perm = (3,1,2,0) on both component indices
-__global__ __launch_bounds__(256) void wino_weight_transpose_kernel(const float *__restrict__ U,
-                                                                    float *__restrict__ Ut, int N,
-                                                                    int C)
-{
-    __shared__ float tile[32][33];
-    const int g = blockIdx.z, gy = g >> 2, gx = g & 3;
-    const int py = gy == 0 ? 3 : gy == 3 ? 0 : gy, px = gx == 0 ? 3 : gx == 3 ? 0 : gx;
-    const float *src = U + (size_t)(py * 4 + px) * N * C;
-    float *dst = Ut + (size_t)g * N * C;
-    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = 0; j < NA; ++j) {
+        const f32x4 col[3] = {t[0][j], t[1][j], t[2][j]};
+        f32x4 u[NA];
+        Wino<F>::g(col, u);                                // along ky
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (n < N && c < C) ? src[(size_t)n * C + c] : 0.f;
-    }
-    __syncthreads();
+        for (int i = 0; i < NA; ++i) {
+            float *o = U + (size_t)(i * NA + j) * plane;
+            if (TRANSPOSED) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i, n = n0 + tx;
-        if (c < C && n < N) dst[(size_t)c * N + n] = tile[tx][ty + 8 * i];
+                for (int e = 0; e < 4; ++e) o[(size_t)(c + e) * N + n] = u[i][e];
+            } else {
+                st4(o + (size_t)n * C + c, u[i]);
+            }
+        }
     }
 }
 
@@ -109,42 +201,41 @@ struct WinoGeom {
 };
 
 // V[g][t][c] = (B^T d B)[g]; one thread per (tile, channel quad), channel quad fastest
-__global__ __launch_bounds__(256) void wino_input_kernel(const GSrc S, const WinoGeom G,
-                                                         float *__restrict__ V)
+template <int F, int NT>
+__global__ __launch_bounds__(NT) void wino_input_kernel(const GSrc S, const WinoGeom G,
+                                                        float *__restrict__ V)
 {
+    constexpr int NA = Wino<F>::NA;
     const int c4n = S.C >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = (long long)blockIdx.x * NT + threadIdx.x;
     if (idx >= (long long)G.T * c4n) return;
     const int t = (int)(idx / c4n), c = (int)(idx - (long long)t * c4n) * 4;
     const int tx = t % G.Tw, r = t / G.Tw, ty = r % G.Th, b = r / G.Th;
     const float *base = S.p + (size_t)b * S.sb + c;
-    f32x4 d[4][4];
+    f32x4 u[NA][NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = 2 * ty - 1 + i;
+    for (int j = 0; j < NA; ++j) {   // column j of the patch: u[.][j] = B^T d[.][j]
+        const int x = F * tx - 1 + j;
+        f32x4 d[NA];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = 2 * tx - 1 + j;
+        for (int i = 0; i < NA; ++i) {
+            const int y = F * ty - 1 + i;
             const bool ok = ((unsigned)y < (unsigned)G.H) & ((unsigned)x < (unsigned)G.W);
-            d[i][j] = ok ? ld4(base + (size_t)y * S.sy + (size_t)x * S.sx) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[i] = ok ? ld4(base + (size_t)y * S.sy + (size_t)x * S.sx) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    }
-    f32x4 u[4][4];
+        f32x4 o[NA];
+        Wino<F>::bt(d, o);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // u = B^T d
-        u[0][j] = d[0][j] - d[2][j];
-        u[1][j] = d[1][j] + d[2][j];
-        u[2][j] = d[2][j] - d[1][j];
-        u[3][j] = d[1][j] - d[3][j];
+        for (int i = 0; i < NA; ++i) u[i][j] = o[i];
     }
     const size_t plane = (size_t)G.T * S.C;
     float *o = V + (size_t)t * S.C + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // V = u B
-        st4(o + (size_t)(4 * i) * plane, u[i][0] - u[i][2]);
-        st4(o + (size_t)(4 * i + 1) * plane, u[i][1] + u[i][2]);
-        st4(o + (size_t)(4 * i + 2) * plane, u[i][2] - u[i][1]);
-        st4(o + (size_t)(4 * i + 3) * plane, u[i][1] - u[i][3]);
+    for (int i = 0; i < NA; ++i) {   // V[i][.] = u[i][.] B
+        f32x4 v[NA];
+        Wino<F>::bt(u[i], v);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) st4(o + (size_t)(i * NA + j) * plane, v[j]);
     }
 }
 
@@ -155,117 +246,122 @@ struct WinoOut {
     int act, bwd_act, N;
 };
 
-// y[b][2ty+dy][2tx+dx][n] = epilogue((A^T m A)[dy][dx]); one thread per (tile, channel quad)
-__global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ Mb,
-                                                          const WinoOut O, const WinoGeom G)
+// y[b][F ty + i][F tx + j][n] = epilogue((A^T m A)[i][j]); one thread per (tile, channel quad)
+template <int F, int NT>
+__global__ __launch_bounds__(NT) void wino_output_kernel(const float *__restrict__ Mb, const WinoOut O,
+                                                         const WinoGeom G)
 {
+    constexpr int NA = Wino<F>::NA;
     const int n4n = O.N >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = (long long)blockIdx.x * NT + threadIdx.x;
     if (idx >= (long long)G.T * n4n) return;
     const int t = (int)(idx / n4n), n = (int)(idx - (long long)t * n4n) * 4;
     const int tx = t % G.Tw, r = t / G.Tw, ty = r % G.Th, b = r / G.Th;
     const size_t plane = (size_t)G.T * O.N;
     const float *mp = Mb + (size_t)t * O.N + n;
-    f32x4 m[4][4];
+    f32x4 s[F][NA];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) m[g >> 2][g & 3] = ld4(mp + (size_t)g * plane);
-    f32x4 s[2][4];
+    for (int j = 0; j < NA; ++j) {   // s[.][j] = A^T m[.][j]
+        f32x4 m[NA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // s = A^T m
-        s[0][j] = m[0][j] + m[1][j] + m[2][j];
-        s[1][j] = m[1][j] - m[2][j] - m[3][j];
+        for (int i = 0; i < NA; ++i) m[i] = ld4(mp + (size_t)(i * NA + j) * plane);
+        f32x4 o[F];
+        Wino<F>::at(m, o);
+#pragma unroll
+        for (int i = 0; i < F; ++i) s[i][j] = o[i];
     }
-    f32x4 v[4];
-    size_t o[4];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (O.bias) bv = ld4(O.bias + n);
+    const size_t o0 = (size_t)b * O.D.sb + (size_t)(F * ty) * O.D.sy + (size_t)(F * tx) * O.D.sx + n;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {   // y = s A
-        v[2 * i] = s[i][0] + s[i][1] + s[i][2];
-        v[2 * i + 1] = s[i][1] - s[i][2] - s[i][3];
+    for (int i = 0; i < F; ++i) {   // one output row at a time: loads, then stores
+        f32x4 v[F];
+        Wino<F>::at(s[i], v);
+        size_t o[F];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            o[2 * i + j] = (size_t)b * O.D.sb + (size_t)(2 * ty + i) * O.D.sy + (size_t)(2 * tx + j) * O.D.sx + n;
-    }
-    if (O.bias) {
-        const f32x4 bv = ld4(O.bias + n);
+        for (int j = 0; j < F; ++j) {
+            o[j] = o0 + (size_t)i * O.D.sy + (size_t)j * O.D.sx;
+            v[j] += bv;
+        }
+        f32x4 a1[F], a2[F], as[F];
+        if (O.D.addend)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bv;
-    }
-    // all optional loads first, then the stores (stores count in vmcnt)
-    f32x4 a1[4], a2[4], as[4];
-    if (O.D.addend)
+            for (int j = 0; j < F; ++j) a1[j] = ld4(O.D.addend + o[j]);
+        if (O.D.addend2)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a1[q] = ld4(O.D.addend + o[q]);
-    if (O.D.addend2)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a2[q] = ld4(O.D.addend2 + o[q]);
-    if (O.D.actsrc)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) as[q] = ld4(O.D.actsrc + o[q]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (O.D.addend) v[q] += a1[q];
-        if (O.D.addend2) v[q] += a2[q];
+            for (int j = 0; j < F; ++j) a2[j] = ld4(O.D.addend2 + o[j]);
         if (O.D.actsrc)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[q][e] *= act_bwd(as[q][e], O.bwd_act);
-    }
-    if (O.zout)
+            for (int j = 0; j < F; ++j) as[j] = ld4(O.D.actsrc + o[j]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) st4(O.zout + o[q], v[q]);
+        for (int j = 0; j < F; ++j) {
+            if (O.D.addend) v[j] += a1[j];
+            if (O.D.addend2) v[j] += a2[j];
+            if (O.D.actsrc)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 y;
+                for (int e = 0; e < 4; ++e) v[j][e] *= act_bwd(as[j][e], O.bwd_act);
+        }
+        if (O.zout)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = act_fwd(v[q][e], O.act);
-        st4(O.D.p + o[q], y);
+            for (int j = 0; j < F; ++j) st4(O.zout + o[j], v[j]);
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = act_fwd(v[j][e], O.act);
+            st4(O.D.p + o[j], y);
+        }
     }
 }
 
-// Z[g][t][n] = (A dY A^T)[g], dY = the tile's 2x2 output gradients (dense NHWC gout)
-__global__ __launch_bounds__(256) void wino_gout_kernel(const float *__restrict__ gout,
-                                                        const WinoGeom G, int N, float *__restrict__ Z)
+// Z[g][t][n] = (A dY A^T)[g], dY = the tile's F x F output gradients (dense NHWC gout)
+template <int F, int NT>
+__global__ __launch_bounds__(NT) void wino_gout_kernel(const float *__restrict__ gout, const WinoGeom G,
+                                                       int N, float *__restrict__ Z)
 {
+    constexpr int NA = Wino<F>::NA;
     const int n4n = N >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = (long long)blockIdx.x * NT + threadIdx.x;
     if (idx >= (long long)G.T * n4n) return;
     const int t = (int)(idx / n4n), n = (int)(idx - (long long)t * n4n) * 4;
     const int tx = t % G.Tw, r = t / G.Tw, ty = r % G.Th, b = r / G.Th;
-    const float *p = gout + (((size_t)b * G.H + 2 * ty) * G.W + 2 * tx) * N + n;
-    const f32x4 d00 = ld4(p), d01 = ld4(p + N), d10 = ld4(p + (size_t)G.W * N),
-                d11 = ld4(p + (size_t)G.W * N + N);
-    // rows of A: (1,0) (1,1) (1,-1) (0,-1)
-    f32x4 u[4][2];
-    u[0][0] = d00;
-    u[0][1] = d01;
-    u[1][0] = d00 + d10;
-    u[1][1] = d01 + d11;
-    u[2][0] = d00 - d10;
-    u[2][1] = d01 - d11;
-    u[3][0] = -d10;
-    u[3][1] = -d11;
+    const float *p = gout + (((size_t)b * G.H + F * ty) * G.W + F * tx) * N + n;
+    f32x4 u[NA][F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) {   // u[.][j] = A dY[.][j]
+        f32x4 d[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i) d[i] = ld4(p + ((size_t)i * G.W + j) * N);
+        f32x4 o[NA];
+        Wino<F>::a(d, o);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) u[i][j] = o[i];
+    }
     const size_t plane = (size_t)G.T * N;
     float *o = Z + (size_t)t * N + n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        st4(o + (size_t)(4 * i) * plane, u[i][0]);
-        st4(o + (size_t)(4 * i + 1) * plane, u[i][0] + u[i][1]);
-        st4(o + (size_t)(4 * i + 2) * plane, u[i][0] - u[i][1]);
-        st4(o + (size_t)(4 * i + 3) * plane, -u[i][1]);
+    for (int i = 0; i < NA; ++i) {
+        f32x4 v[NA];
+        Wino<F>::a(u[i], v);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) st4(o + (size_t)(i * NA + j) * plane, v[j]);
     }
 }
 
 // dW[n][3][3][c] = G^T (sum over the S slabs of dU[g][s][n][c]) G; the trailing
-// workgroups add the S column-sum partials of component 5 into dbias.
+// workgroups add the S column-sum partials of component (1,1) into dbias.
+template <int F>
 __global__ __launch_bounds__(256) void wino_dw_kernel(const float *__restrict__ dU, int S, int N, int C,
                                                       float *__restrict__ dW, int nb_main,
                                                       const float *__restrict__ bias_part,
                                                       float *__restrict__ dbias)
 {
+    constexpr int NA = Wino<F>::NA;
     if ((int)blockIdx.x >= nb_main) {
         const int n = ((int)blockIdx.x - nb_main) * 256 + threadIdx.x;
         if (n < N) {
             float v = 0.f;
-            for (int s = 0; s < S; ++s) v += bias_part[(size_t)(5 * S + s) * N + n];
+            for (int s = 0; s < S; ++s) v += bias_part[(size_t)((NA + 1) * S + s) * N + n];
             dbias[n] = v;
         }
         return;
@@ -275,36 +371,62 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float *__restrict__ 
     if (idx >= (long long)N * c4n) return;
     const int n = (int)(idx / c4n), c = (int)(idx - (long long)n * c4n) * 4;
     const size_t plane = (size_t)N * C;
-    f32x4 m[4][4];
+    f32x4 t[3][NA];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const float *p = dU + (size_t)g * S * plane + (size_t)n * C + c;
-        f32x4 v = ld4(p);
-        for (int s = 1; s < S; ++s) v += ld4(p + (size_t)s * plane);
-        m[g >> 2][g & 3] = v;
-    }
-    // rows of G^T: (1,.5,.5,0) (0,.5,-.5,0) (0,.5,.5,1)
-    f32x4 t[3][4];
+    for (int j = 0; j < NA; ++j) {   // t[.][j] = G^T m[.][j]
+        f32x4 m[NA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        t[0][j] = m[0][j] + 0.5f * (m[1][j] + m[2][j]);
-        t[1][j] = 0.5f * (m[1][j] - m[2][j]);
-        t[2][j] = 0.5f * (m[1][j] + m[2][j]) + m[3][j];
+        for (int i = 0; i < NA; ++i) {
+            const float *p = dU + (size_t)(i * NA + j) * S * plane + (size_t)n * C + c;
+            f32x4 v = ld4(p);
+            for (int s = 1; s < S; ++s) v += ld4(p + (size_t)s * plane);
+            m[i] = v;
+        }
+        f32x4 o[3];
+        Wino<F>::gt(m, o);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i][j] = o[i];
     }
     float *o = dW + (size_t)n * 9 * C + c;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        st4(o + (size_t)(3 * i) * C, t[i][0] + 0.5f * (t[i][1] + t[i][2]));
-        st4(o + (size_t)(3 * i + 1) * C, 0.5f * (t[i][1] - t[i][2]));
-        st4(o + (size_t)(3 * i + 2) * C, 0.5f * (t[i][1] + t[i][2]) + t[i][3]);
+        f32x4 v[3];
+        Wino<F>::gt(t[i], v);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) st4(o + (size_t)(3 * i + j) * C, v[j]);
     }
 }
 
+inline int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+inline unsigned nblocks(long long n, int nt) { return (unsigned)((n + nt - 1) / nt); }
+
 }  // namespace
 
+// Output tile side of the forward / data-gradient evaluation: 4 when the image
+// allows it (DVSOF_WINO_F=2 forces the 2x2 form).
+// The bf16x3 operand mode (mfma = 2, ~2^-16 per product) stays with the 2x2
+// form: the 4x4 transforms amplify the product error past its 1e-4 test bound.
+int wino_tile(int H, int W, int mfma)
+{
+    static const int f_env = env_int("DVSOF_WINO_F", 0);
+    if (f_env == 2 || mfma != 0) return 2;
+    return ((H % 4) == 0 && (W % 4) == 0) ? 4 : 2;
+}
+
+int wino_components(int H, int W, int mfma)
+{
+    const int f = wino_tile(H, W, mfma);
+    return (f + 2) * (f + 2);
+}
+
 // A 3x3 / stride-1 / pad-1 problem over one dense NHWC source whose channel
-// counts make the transforms' memory traffic (32 (C + N) bytes per output pixel)
-// cheaper than the 5/9 of the matrix work they save: C N / (C + N) > ~100.
+// counts make the transforms' memory traffic (~32 (C + N) bytes per output pixel
+// for the 2x2 form) cheaper than the matrix work they save: C N / (C + N) > ~100.
 bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int H, int W, int ksize, int stride,
                          int pad, int upsample, int mfma)
 {
@@ -316,44 +438,43 @@ bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int H, int W, 
     return C >= 256 && N >= 256;
 }
 
-size_t wino_scratch_floats(int B, int H, int W, int C, int N)
+size_t wino_scratch_floats(int B, int H, int W, int C, int N, int mfma)
 {
-    return (size_t)16 * B * (H / 2) * (W / 2) * ((size_t)C + N);
+    const int f = wino_tile(H, W, mfma);
+    return (size_t)(f + 2) * (f + 2) * B * (H / f) * (W / f) * ((size_t)C + N);
 }
 
-int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, hipStream_t st)
+// U (forward form) and / or Ut (data-gradient form) from the raw weights
+int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int H, int W, int mfma,
+                 hipStream_t st)
 {
-    if (weight) {
-        if (!U) return DVSOF_EINVAL;
-        const long long n = (long long)N * (C / 4);
-        hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           weight, U, N, C);
+    if (!weight) return DVSOF_EINVAL;
+    const int f = wino_tile(H, W, mfma);
+    const unsigned nb = nblocks((long long)N * (C / 4), 256);
+    if (U) {
+        if (f == 4) hipLaunchKernelGGL((wino_weight_kernel<4, false>), dim3(nb), dim3(256), 0, st, weight, U, N, C);
+        else hipLaunchKernelGGL((wino_weight_kernel<2, false>), dim3(nb), dim3(256), 0, st, weight, U, N, C);
         DVSOF_LAUNCH_CHECK();
     }
     if (Ut) {
-        if (!U) return DVSOF_EINVAL;
-        hipLaunchKernelGGL(wino_weight_transpose_kernel, dim3((C + 31) / 32, (N + 31) / 32, 16),
-                           dim3(256), 0, st, (const float *)U, Ut, N, C);
+        if (f == 4) hipLaunchKernelGGL((wino_weight_kernel<4, true>), dim3(nb), dim3(256), 0, st, weight, Ut, N, C);
+        else hipLaunchKernelGGL((wino_weight_kernel<2, true>), dim3(nb), dim3(256), 0, st, weight, Ut, N, C);
         DVSOF_LAUNCH_CHECK();
     }
     return DVSOF_OK;
 }
 
-// P: the direct problem (3x3, stride 1, pad 1, one NHWC source, one destination)
-// with P.W = U[16][N][C].
-int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st)
+template <int F>
+static int wino_launch_f(const GConvParams &P, float *scratch, hipStream_t st)
 {
+    constexpr int NA = Wino<F>::NA, NG = NA * NA;
+    constexpr int NT = F == 4 ? 64 : 256;   // the 4x4 form has 4x fewer threads: smaller workgroups
     const int C = P.Cin_tot, N = P.N;
-    if (P.nsrc != 1 || P.ndst != 1 || P.src[0].flat || P.src[0].sc != 1 || P.dst[0].sc != 1 ||
-        P.dst[0].C != N || P.src[0].C != C || P.Ho != P.Hv || P.Wo != P.Wv)
-        return DVSOF_EINVAL;
-    WinoGeom G = {P.B, P.Hv, P.Wv, P.Hv / 2, P.Wv / 2, P.B * (P.Hv / 2) * (P.Wv / 2)};
-    if (!scratch || scratch_floats < wino_scratch_floats(P.B, P.Hv, P.Wv, C, N)) return DVSOF_ENOSPACE;
-    float *V = scratch, *Mb = scratch + (size_t)16 * G.T * C;
+    WinoGeom G = {P.B, P.Hv, P.Wv, P.Hv / F, P.Wv / F, P.B * (P.Hv / F) * (P.Wv / F)};
+    float *V = scratch, *Mb = scratch + (size_t)NG * G.T * C;
 
-    const long long nin = (long long)G.T * (C / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st,
-                       P.src[0], G, V);
+    hipLaunchKernelGGL((wino_input_kernel<F, NT>), dim3(nblocks((long long)G.T * (C / 4), NT)), dim3(NT), 0,
+                       st, P.src[0], G, V);
     DVSOF_LAUNCH_CHECK();
 
     GConvParams Q = {};
@@ -373,7 +494,7 @@ int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hip
     Q.stride = 1;
     Q.pad = 0;
     Q.ks = 1;
-    Q.nph = 16;
+    Q.nph = NG;
     Q.ph_pad = 0;
     Q.w_phase_stride = (long long)N * C;
     Q.N = N;
@@ -382,57 +503,91 @@ int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hip
     Q.act = ACT_NONE;
     Q.bwd_act = ACT_NONE;
     Q.mfma_bf16 = P.mfma_bf16;
-    if ((long long)16 * G.T * N * 4 >= 0x7fffffffLL || (long long)G.T * N >= 0x3fffffffLL ||
-        !gconv2_eligible(Q, (long long)G.T * C * 4, (long long)16 * N * C * 4))
+    if ((long long)NG * G.T * N * 4 >= 0x7fffffffLL ||
+        !gconv2_eligible(Q, (long long)G.T * C * 4, (long long)NG * N * C * 4))
         return DVSOF_EINVAL;
-    static const int tile = getenv("DVSOF_WINO_TILE") ? atoi(getenv("DVSOF_WINO_TILE")) : 3;   // tuning
+    static const int tile = env_int("DVSOF_WINO_TILE", 3);   // tuning
     const int rc = gconv2_launch(Q, tile, st);
     if (rc) return rc;
 
     WinoOut O = {P.dst[0], P.bias, P.zout, P.act, P.bwd_act, N};
-    const long long nout = (long long)G.T * (N / 4);
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st,
-                       (const float *)Mb, O, G);
+    hipLaunchKernelGGL((wino_output_kernel<F, NT>), dim3(nblocks((long long)G.T * (N / 4), NT)), dim3(NT), 0,
+                       st, (const float *)Mb, O, G);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
 
+// P: the direct problem (3x3, stride 1, pad 1, one NHWC source, one destination)
+// with P.W = U[NG][N][C].
+int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st)
+{
+    const int C = P.Cin_tot, N = P.N;
+    if (P.nsrc != 1 || P.ndst != 1 || P.src[0].flat || P.src[0].sc != 1 || P.dst[0].sc != 1 ||
+        P.dst[0].C != N || P.src[0].C != C || P.Ho != P.Hv || P.Wo != P.Wv)
+        return DVSOF_EINVAL;
+    if (!scratch || scratch_floats < wino_scratch_floats(P.B, P.Hv, P.Wv, C, N, P.mfma_bf16))
+        return DVSOF_ENOSPACE;
+    return wino_tile(P.Hv, P.Wv, P.mfma_bf16) == 4 ? wino_launch_f<4>(P, scratch, st) : wino_launch_f<2>(P, scratch, st);
+}
+
+// ---- weight gradient
+// Output tile side: the tile count is the K dimension of the GEMMs, so the 4x4
+// form (4x fewer tiles, 2.25x more components to write and fold) only pays
+// with enough tiles: measured 57 vs 62 us at 128 tiles (batch 8, 16x16, 512
+// channels).  DVSOF_WINO_WGRAD_F overrides.  0: not available.
+int wino_wgrad_tile(int B, int H, int W, int mfma)
+{
+    static const int f_env = env_int("DVSOF_WINO_WGRAD_F", 0);
+    static const int min_t4 = env_int("DVSOF_WINO_WGRAD_F4_MIN_TILES", 128);
+    const bool ok2 = !(H & 1) && !(W & 1) && (B * (H / 2) * (W / 2)) % BK == 0;
+    const bool ok4 = mfma == 0 && !(H & 3) && !(W & 3) && (B * (H / 4) * (W / 4)) % BK == 0;
+    if (f_env == 2) return ok2 ? 2 : 0;
+    if (f_env == 4) return ok4 ? 4 : ok2 ? 2 : 0;
+    if (ok4 && B * (H / 4) * (W / 4) >= min_t4) return 4;
+    return ok2 ? 2 : ok4 ? 4 : 0;
+}
+
 // K splits of the weight-gradient GEMMs (K = tiles): enough workgroups for two
 // per CU with 64 x 128 tiles, at least 16 K steps each
-static int wino_wgrad_splits(int T, int N, int C)
+static int wino_wgrad_splits(int NG, int T, int N, int C)
 {
-    static const int s_env = getenv("DVSOF_WINO_WGRAD_SPLITS") ? atoi(getenv("DVSOF_WINO_WGRAD_SPLITS")) : 0;
+    static const int s_env = env_int("DVSOF_WINO_WGRAD_SPLITS", 0);
     int S = 1;
     if (s_env > 0) S = s_env;
     else {
-        const long long tiles = (long long)16 * ((N + 63) / 64) * ((C + 127) / 128);
+        const long long tiles = (long long)NG * ((N + 63) / 64) * ((C + 127) / 128);
         while (tiles * S < 512 && T / (S * 2) >= 16 * BK) S *= 2;
     }
     while (S > 1 && (T + S - 1) / S < BK) --S;
     return S;
 }
 
-size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N)
+size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N, int mfma)
 {
-    const size_t T = (size_t)B * (H / 2) * (W / 2);
-    const int S = wino_wgrad_splits((int)T, N, C);
-    return 16 * T * ((size_t)C + N) + (size_t)16 * S * N * C + (size_t)16 * S * N;
+    const int f = wino_wgrad_tile(B, H, W, mfma);
+    if (f == 0) return 0;
+    const int NG = (f + 2) * (f + 2);
+    const size_t T = (size_t)B * (H / f) * (W / f);
+    const int S = wino_wgrad_splits(NG, (int)T, N, C);
+    return NG * T * ((size_t)C + N) + (size_t)NG * S * N * C + (size_t)NG * S * N;
 }
 
-int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
-                      int C, int N, int mfma_bf16, float *ws, size_t ws_floats, hipStream_t st)
+template <int F>
+static int wino_wgrad_f(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
+                        int C, int N, int mfma_bf16, float *ws, hipStream_t st)
 {
-    if (X.flat || X.sc != 1 || X.C != C) return DVSOF_EINVAL;
-    WinoGeom G = {B, H, W, H / 2, W / 2, B * (H / 2) * (W / 2)};
-    if (!ws || ws_floats < wino_wgrad_workspace_floats(B, H, W, C, N)) return DVSOF_ENOSPACE;
-    const int S = wino_wgrad_splits(G.T, N, C);
-    float *V = ws, *Z = V + (size_t)16 * G.T * C, *dU = Z + (size_t)16 * G.T * N;
-    float *bias_part = dU + (size_t)16 * S * N * C;
+    constexpr int NA = Wino<F>::NA, NG = NA * NA;
+    constexpr int NT = F == 4 ? 64 : 256;
+    WinoGeom G = {B, H, W, H / F, W / F, B * (H / F) * (W / F)};
+    const int S = wino_wgrad_splits(NG, G.T, N, C);
+    float *V = ws, *Z = V + (size_t)NG * G.T * C, *dU = Z + (size_t)NG * G.T * N;
+    float *bias_part = dU + (size_t)NG * S * N * C;
 
-    const long long nin = (long long)G.T * (C / 4), ng = (long long)G.T * (N / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, X, G, V);
+    hipLaunchKernelGGL((wino_input_kernel<F, NT>), dim3(nblocks((long long)G.T * (C / 4), NT)), dim3(NT), 0,
+                       st, X, G, V);
     DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wino_gout_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, gout, G, N, Z);
+    hipLaunchKernelGGL((wino_gout_kernel<F, NT>), dim3(nblocks((long long)G.T * (N / 4), NT)), dim3(NT), 0,
+                       st, gout, G, N, Z);
     DVSOF_LAUNCH_CHECK();
 
     WGradParams Q = {};
@@ -459,23 +614,33 @@ int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias,
     Q.g_sx = N;
     Q.g_py = 2 * G.T * N;   // phase g = 2 phy + phx -> plane g of Z
     Q.g_px = G.T * N;
-    Q.nph = 16;
+    Q.nph = NG;
     Q.ph_pad = 0;
     Q.mfma_bf16 = mfma_bf16;
-    static const int tile = getenv("DVSOF_WINO_WGRAD_TILE") ? atoi(getenv("DVSOF_WINO_WGRAD_TILE")) : 4;
+    static const int tile = env_int("DVSOF_WINO_WGRAD_TILE", 3);
     const int bn = (tile == 2 || tile == 3) ? 64 : 128;
     const int nt = (C + bn - 1) / bn;
     Q.tile_begin[0] = 0;
     Q.tile_begin[1] = nt;
-    if ((G.T % BK) || (long long)16 * G.T * (C > N ? C : N) * 4 >= 0x7fffffffLL || !wgrad2_eligible(Q))
+    if ((G.T % BK) || (long long)NG * G.T * (C > N ? C : N) * 4 >= 0x7fffffffLL || !wgrad2_eligible(Q))
         return DVSOF_EINVAL;
     const int rc = wgrad2_launch(Q, tile, nt, st);
     if (rc) return rc;
 
-    const long long nw = (long long)N * (C / 4);
-    const int nb_main = (int)((nw + 255) / 256), nb_bias = dbias ? (N + 255) / 256 : 0;
-    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)(nb_main + nb_bias)), dim3(256), 0, st,
+    const int nb_main = (int)nblocks((long long)N * (C / 4), 256), nb_bias = dbias ? (N + 255) / 256 : 0;
+    hipLaunchKernelGGL((wino_dw_kernel<F>), dim3((unsigned)(nb_main + nb_bias)), dim3(256), 0, st,
                        (const float *)dU, S, N, C, dW, nb_main, (const float *)bias_part, dbias);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
+}
+
+int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
+                      int C, int N, int mfma_bf16, float *ws, size_t ws_floats, hipStream_t st)
+{
+    if (X.flat || X.sc != 1 || X.C != C) return DVSOF_EINVAL;
+    const int f = wino_wgrad_tile(B, H, W, mfma_bf16);
+    if (f == 0) return DVSOF_EINVAL;
+    if (!ws || ws_floats < wino_wgrad_workspace_floats(B, H, W, C, N, mfma_bf16)) return DVSOF_ENOSPACE;
+    return f == 4 ? wino_wgrad_f<4>(X, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st)
+                  : wino_wgrad_f<2>(X, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st);
 }

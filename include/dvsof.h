@@ -274,13 +274,16 @@ typedef struct {
  * Bytes of scratch dvsof_conv2d_fwd / dvsof_conv2d_dgrad need for this layer:
  * non-zero for the wide 3x3 stride-1 layers (one NHWC source, channel counts
  * multiples of 64 and >= 256, even H and W, mfma != 1), which are evaluated as
- * Winograd F(2x2,3x3): input transform, 16 component GEMMs on the matrix
- * cores, output transform with the fused epilogue -- 2.25x fewer multiply-adds,
- * same result up to fp32 rounding of the transforms (~1e-6 relative).  Their
- * prepared weights are U[16][Cout][Ctot] forward and U'[16][Ctot][Cout]
- * backward (dvsof_conv2d_prepare; as for a sub-pixel layer, weight == NULL
- * derives U' from an existing U).  The scratch holds the transformed input
- * and the component products; it is only used during the call.
+ * Winograd convolutions -- F(4x4,3x3) when H and W are multiples of 4 (4x fewer
+ * multiply-adds), else F(2x2,3x3) (2.25x fewer): input transform, NG = 36 | 16
+ * component GEMMs on the matrix cores, output transform with the fused
+ * epilogue.  Same result up to fp32 rounding of the transforms (~1e-5 | ~1e-6
+ * of the output peak).  Their prepared weights are U[NG][Cout][Ctot] forward
+ * and U'[NG][Ctot][Cout] backward; dvsof_conv2d_prepare makes either or both
+ * from the raw weights (weight must not be NULL for these layers).  The
+ * scratch holds the transformed input and the component products; it is only
+ * used during the call.  The weight gradient of such a layer runs through the
+ * same transforms inside its ordinary workspace.
  */
 size_t dvsof_conv2d_scratch_bytes(const dvsof_conv_desc_t *desc);
 

@@ -46,6 +46,8 @@ CASES = [
     dict(B=1, H=4, W=4, src=[(320, 'nhwc')], Cout=256, stride=1, act='mish', wino=True),
     # ... and weight gradient (tile count a multiple of 16)
     dict(B=3, H=8, W=16, src=[(256, 'nhwc')], Cout=384, stride=1, wino=True),
+    # >= 128 4x4 tiles: the weight gradient takes the F(4x4,3x3) form too
+    dict(B=8, H=16, W=16, src=[(256, 'nhwc')], Cout=256, stride=1, wino=True),
 ]
 
 
