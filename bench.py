@@ -41,8 +41,13 @@ TILE_SHAPES = {
 }
 
 
-def kernel_name(family, tile, gen):
+def kernel_name(family, tile, gen, wino=0):
     """Name as rocprofv3 reports it (kernel template + tile shape)."""
+    if wino:
+        # input / gradient transforms + NG component GEMMs + output transform
+        ng = (wino + 2) ** 2
+        gemm = 'gconv2_kernel<2,2,1,1> 64x64' if family == 'gconv' else 'wgrad2_kernel<2,2,1,1> 64x64'
+        return f'winograd F({wino}x{wino},3x3) {family}: wino_*_kernel + {gemm} x{ng}'
     if gen == 0:
         return 'wgrad_flat_kernel (VALU, flat members)'
     # (gconv2 instantiations carry two more template arguments in rocprof
@@ -131,9 +136,14 @@ def executed_flops(desc, kind):
     """FLOPs the MFMA kernels actually issue: the sub-pixel decomposition of
     upsample+3x3 runs 16 instead of 36 tap-products (the phased stride-2 data
     gradient runs exactly its 9: phase (py,px) has (1+py)(1+px) taps)."""
+    import ctypes
+    from dvs_of_training_framework_amd import conv as C
     f = conv_flops(desc, kind)
     if desc.upsample and desc.ksize == 3 and desc.pad == 1:
         return f * 16.0 / 36.0
+    m = C._lib.lib().dvsof_conv2d_winograd_tile(ctypes.byref(desc), kind)
+    if m:   # (m+2)^2 products per m x m outputs instead of 9 m^2
+        return f * (m + 2) ** 2 / (9.0 * m * m)
     return f
 
 
@@ -171,12 +181,13 @@ def measure_roofline(h, step_ms, steps=3):
             import ctypes
             tile = lib.dvsof_conv2d_tile_id(ctypes.byref(desc), kind)
             gen = lib.dvsof_conv2d_kernel_generation(ctypes.byref(desc), kind)
+            wino = lib.dvsof_conv2d_winograd_tile(ctypes.byref(desc), kind)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(desc, *args, **kw)
             e1.record()
-            records.append((kernel_name(family, tile, gen), conv_flops(desc, kind),
+            records.append((kernel_name(family, tile, gen, wino), conv_flops(desc, kind),
                             e0, e1, executed_flops(desc, kind)))
             return out
         return inner

@@ -24,7 +24,8 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [('src', Src * 3), ('nsrc', _i), ('B', _i), ('H', _i),
                 ('W', _i), ('upsample', _i), ('ksize', _i), ('stride', _i),
                 ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i),
-                ('scratch', _vp), ('scratch_bytes', _sz)]
+                ('scratch', _vp), ('scratch_bytes', _sz),
+                ('winograd_input', _vp)]
 
 
 class GradDst(ctypes.Structure):
@@ -55,6 +56,7 @@ _lib.register('dvsof_conv2d_fwd_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_dgrad_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])
 _lib.register('dvsof_conv2d_scratch_bytes', _sz, [_P(ConvDesc)])
+_lib.register('dvsof_conv2d_winograd_tile', _i, [_P(ConvDesc), _i])
 
 
 MFMA_F32, MFMA_BF16, MFMA_BF16X3 = 0, 1, 2
@@ -96,8 +98,11 @@ def _scratch(desc, device):
     return t
 
 
-def conv_fwd(desc, weight, bias, device, residual=None, want_z=False):
-    """-> y [B,Ho,Wo,Cout] (NHWC buffer), z or None."""
+def conv_fwd(desc, weight, bias, device, residual=None, want_z=False,
+             keep_input_transform=False):
+    """-> y [B,Ho,Wo,Cout] (NHWC buffer), z or None.
+    keep_input_transform: a Winograd layer's scratch (it starts with the
+    transformed input) stays attached to ``desc`` for conv_wgrad."""
     ho, wo = out_size(desc)
     y = torch.empty(desc.B, ho, wo, desc.Cout, dtype=torch.float32,
                     device=device)
@@ -107,6 +112,7 @@ def conv_fwd(desc, weight, bias, device, residual=None, want_z=False):
         ctypes.byref(desc), weight.data_ptr(), _lib.ptr(bias),
         _lib.ptr(residual), y.data_ptr(), _lib.ptr(z), _lib.stream()),
         'dvsof_conv2d_fwd')
+    desc._wino_input = ws if keep_input_transform else None
     return y, z
 
 
@@ -170,6 +176,8 @@ def conv_wgrad(desc, gout, dweight, dbias):
     nbytes = _lib.lib().dvsof_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32,
                      device=gout.device)
+    kept = getattr(desc, '_wino_input', None)
+    desc.winograd_input = kept.data_ptr() if kept is not None else None
     _lib.check(_lib.lib().dvsof_conv2d_wgrad(
         ctypes.byref(desc), gout.data_ptr(), dweight.data_ptr(),
         _lib.ptr(dbias), ws.data_ptr(), ws.numel() * 4, _lib.stream()),

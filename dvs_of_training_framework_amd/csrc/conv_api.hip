@@ -11,17 +11,19 @@ size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat);
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias);
 int gconv_pick_tile(long long m, long long n);
 int wgrad_splits(const WGradParams &P0, int *tile_out);
-bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int H, int W, int ksize, int stride,
-                         int pad, int upsample, int mfma);
-int wino_components(int H, int W, int mfma);
+bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int B, int H, int W, int ksize,
+                         int stride, int pad, int upsample, int mfma);
+int wino_components(int B, int H, int W, int mfma);
 size_t wino_scratch_floats(int B, int H, int W, int C, int N, int mfma);
-int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int H, int W, int mfma,
+int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int B, int H, int W, int mfma,
                  hipStream_t st);
 int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st);
 int wino_wgrad_tile(int B, int H, int W, int mfma);
 size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N, int mfma);
-int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
-                      int C, int N, int mfma_bf16, float *ws, size_t ws_floats, hipStream_t st);
+int wino_tile(int B, int H, int W, int mfma);
+int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *gout, float *dW, float *dbias, int B,
+                      int H, int W, int C, int N, int mfma_bf16, float *ws, size_t ws_floats,
+                      hipStream_t st);
 
 namespace {
 
@@ -76,8 +78,8 @@ bool is_subpixel(const dvsof_conv_desc_t *d)
 bool is_wino(const dvsof_conv_desc_t *d)
 {
     return d->nsrc == 1 &&
-           wino_eligible_shape(d->nsrc, d->src[0].layout == DVSOF_NHWC, d->src[0].C, d->Cout, d->H,
-                               d->W, d->ksize, d->stride, d->pad, d->upsample, d->mfma);
+           wino_eligible_shape(d->nsrc, d->src[0].layout == DVSOF_NHWC, d->src[0].C, d->Cout, d->B,
+                               d->H, d->W, d->ksize, d->stride, d->pad, d->upsample, d->mfma);
 }
 
 // ... and its weight gradient too: the tile count is the K dimension of the
@@ -600,10 +602,15 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo) || !gout || !dweight) return DVSOF_EINVAL;
     if (is_wino_wgrad(d))
-        return wino_wgrad_launch(make_src(d->src[0].p, d->src[0].C, d->src[0].layout, d->H, d->W), gout,
-                                 dweight, dbias, d->B, d->H, d->W, Ctot, d->Cout,
-                                 d->mfma == 2 ? 2 : 0, (float *)ws, ws_bytes / sizeof(float),
-                                 as_stream(stream));
+    {
+        // the forward's transformed input, when the caller kept it and both use the same form
+        const int mf = d->mfma == 2 ? 2 : 0;
+        const float *v_in = wino_tile(d->B, d->H, d->W, mf) == wino_wgrad_tile(d->B, d->H, d->W, mf)
+                                ? d->winograd_input : nullptr;
+        return wino_wgrad_launch(make_src(d->src[0].p, d->src[0].C, d->src[0].layout, d->H, d->W), v_in,
+                                 gout, dweight, dbias, d->B, d->H, d->W, Ctot, d->Cout, mf, (float *)ws,
+                                 ws_bytes / sizeof(float), as_stream(stream));
+    }
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
     P.gout = gout;
@@ -619,7 +626,7 @@ size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
-    if (is_wino(d)) return (size_t)d->Cout * Ctot * wino_components(d->H, d->W, d->mfma == 2 ? 2 : 0);
+    if (is_wino(d)) return (size_t)d->Cout * Ctot * wino_components(d->B, d->H, d->W, d->mfma == 2 ? 2 : 0);
     return (size_t)d->Cout * Ctot * (is_subpixel(d) ? 16 : d->ksize * d->ksize);
 }
 
@@ -627,7 +634,7 @@ size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
-    if (is_wino(d)) return (size_t)d->Cout * Ctot * wino_components(d->H, d->W, d->mfma == 2 ? 2 : 0);
+    if (is_wino(d)) return (size_t)d->Cout * Ctot * wino_components(d->B, d->H, d->W, d->mfma == 2 ? 2 : 0);
     if (is_subpixel(d) || is_stride2_phased(d)) return (size_t)d->Cout * Ctot * 16;
     return (size_t)d->Cout * Ctot * d->ksize * d->ksize;
 }
@@ -659,7 +666,7 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
     }
     if (is_wino(d)) {   // either form (or both) from the raw weights
         if (!weight || (!w_fwd && !w_dgrad)) return DVSOF_EINVAL;
-        return wino_prepare(weight, w_fwd, w_dgrad, d->Cout, Ctot, d->H, d->W, d->mfma == 2 ? 2 : 0, st);
+        return wino_prepare(weight, w_fwd, w_dgrad, d->Cout, Ctot, d->B, d->H, d->W, d->mfma == 2 ? 2 : 0, st);
     }
     if (!weight) return DVSOF_EINVAL;
     if (is_stride2_phased(d) && w_dgrad) {
@@ -680,6 +687,16 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
 }
 
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind);
+
+// 0: direct implicit GEMM; 2 | 4: Winograd F(2x2,3x3) | F(4x4,3x3) (kind 0 fwd, 1 dgrad, 2 wgrad)
+int dvsof_conv2d_winograd_tile(const dvsof_conv_desc_t *d, int kind)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo) || !is_wino(d)) return 0;
+    const int mfma = d->mfma == 2 ? 2 : 0;
+    if (kind == 2) return is_wino_wgrad(d) ? wino_wgrad_tile(d->B, d->H, d->W, mfma) : 0;
+    return wino_tile(d->B, d->H, d->W, mfma);
+}
 
 // 2 when the LDS-DMA (v2) kernel serves this problem's vector members, else 1
 int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *d, int kind)

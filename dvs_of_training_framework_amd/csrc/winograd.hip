@@ -50,6 +50,41 @@ namespace {
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *(const f32x4 *)p; }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *(f32x4 *)p = v; }
 
+// element type of the transform kernels: VW = 4 channels per thread (16-byte
+// accesses) or 1 (4x the threads; the small problems are latency bound)
+template <int VW>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef f32x4 T;
+    static __device__ __forceinline__ T ld(const float *p) { return *(const f32x4 *)p; }
+    static __device__ __forceinline__ void st(float *p, T v) { *(f32x4 *)p = v; }
+    static __device__ __forceinline__ T zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ T actf(T v, int act)
+    {
+        T y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = act_fwd(v[e], act);
+        return y;
+    }
+    static __device__ __forceinline__ T actb(T s, int act)
+    {
+        T y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = act_bwd(s[e], act);
+        return y;
+    }
+};
+template <>
+struct Vec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, T v) { *p = v; }
+    static __device__ __forceinline__ T zero() { return 0.f; }
+    static __device__ __forceinline__ T actf(T v, int act) { return act_fwd(v, act); }
+    static __device__ __forceinline__ T actb(T s, int act) { return act_bwd(s, act); }
+};
+
 // ---- the 1-D transforms (F = output tile side m; NA = m + 2 points)
 template <int F>
 struct Wino;
@@ -58,7 +93,8 @@ template <>
 struct Wino<2> {
     static constexpr int NA = 4;
     // B^T: data
-    static __device__ __forceinline__ void bt(const f32x4 (&d)[4], f32x4 (&o)[4])
+    template <typename T>
+    static __device__ __forceinline__ void bt(const T (&d)[4], T (&o)[4])
     {
         o[0] = d[0] - d[2];
         o[1] = d[1] + d[2];
@@ -66,7 +102,8 @@ struct Wino<2> {
         o[3] = d[1] - d[3];
     }
     // G: kernel taps -> points
-    static __device__ __forceinline__ void g(const f32x4 (&w)[3], f32x4 (&o)[4])
+    template <typename T>
+    static __device__ __forceinline__ void g(const T (&w)[3], T (&o)[4])
     {
         o[0] = w[0];
         o[1] = 0.5f * (w[0] + w[1] + w[2]);
@@ -74,13 +111,15 @@ struct Wino<2> {
         o[3] = w[2];
     }
     // A^T: points -> outputs
-    static __device__ __forceinline__ void at(const f32x4 (&m)[4], f32x4 (&o)[2])
+    template <typename T>
+    static __device__ __forceinline__ void at(const T (&m)[4], T (&o)[2])
     {
         o[0] = m[0] + m[1] + m[2];
         o[1] = m[1] - m[2] - m[3];
     }
     // A: output gradients -> points
-    static __device__ __forceinline__ void a(const f32x4 (&y)[2], f32x4 (&o)[4])
+    template <typename T>
+    static __device__ __forceinline__ void a(const T (&y)[2], T (&o)[4])
     {
         o[0] = y[0];
         o[1] = y[0] + y[1];
@@ -88,7 +127,8 @@ struct Wino<2> {
         o[3] = -y[1];
     }
     // G^T: points -> kernel-tap gradients
-    static __device__ __forceinline__ void gt(const f32x4 (&m)[4], f32x4 (&o)[3])
+    template <typename T>
+    static __device__ __forceinline__ void gt(const T (&m)[4], T (&o)[3])
     {
         o[0] = m[0] + 0.5f * (m[1] + m[2]);
         o[1] = 0.5f * (m[1] - m[2]);
@@ -99,7 +139,8 @@ struct Wino<2> {
 template <>
 struct Wino<4> {
     static constexpr int NA = 6;
-    static __device__ __forceinline__ void bt(const f32x4 (&d)[6], f32x4 (&o)[6])
+    template <typename T>
+    static __device__ __forceinline__ void bt(const T (&d)[6], T (&o)[6])
     {
         o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
         o[1] = (d[3] + d[4]) - 4.f * (d[1] + d[2]);
@@ -108,10 +149,11 @@ struct Wino<4> {
         o[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
         o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
     }
-    static __device__ __forceinline__ void g(const f32x4 (&w)[3], f32x4 (&o)[6])
+    template <typename T>
+    static __device__ __forceinline__ void g(const T (&w)[3], T (&o)[6])
     {
-        const f32x4 s = w[0] + w[2];
-        const f32x4 q = (1.f / 24.f) * w[0] + (1.f / 6.f) * w[2], h = (1.f / 12.f) * w[1];
+        const T s = w[0] + w[2];
+        const T q = (1.f / 24.f) * w[0] + (1.f / 6.f) * w[2], h = (1.f / 12.f) * w[1];
         o[0] = 0.25f * w[0];
         o[1] = (-1.f / 6.f) * (s + w[1]);
         o[2] = (-1.f / 6.f) * (s - w[1]);
@@ -119,18 +161,20 @@ struct Wino<4> {
         o[4] = q - h;
         o[5] = w[2];
     }
-    static __device__ __forceinline__ void at(const f32x4 (&m)[6], f32x4 (&o)[4])
+    template <typename T>
+    static __device__ __forceinline__ void at(const T (&m)[6], T (&o)[4])
     {
-        const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        const T s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
         o[0] = m[0] + s12 + s34;
         o[1] = d12 + 2.f * d34;
         o[2] = s12 + 4.f * s34;
         o[3] = d12 + 8.f * d34 + m[5];
     }
-    static __device__ __forceinline__ void a(const f32x4 (&y)[4], f32x4 (&o)[6])
+    template <typename T>
+    static __device__ __forceinline__ void a(const T (&y)[4], T (&o)[6])
     {
-        const f32x4 e = y[0] + y[2], f = y[1] + y[3];
-        const f32x4 e4 = y[0] + 4.f * y[2], f4 = 2.f * y[1] + 8.f * y[3];
+        const T e = y[0] + y[2], f = y[1] + y[3];
+        const T e4 = y[0] + 4.f * y[2], f4 = 2.f * y[1] + 8.f * y[3];
         o[0] = y[0];
         o[1] = e + f;
         o[2] = e - f;
@@ -138,9 +182,10 @@ struct Wino<4> {
         o[4] = e4 - f4;
         o[5] = y[3];
     }
-    static __device__ __forceinline__ void gt(const f32x4 (&m)[6], f32x4 (&o)[3])
+    template <typename T>
+    static __device__ __forceinline__ void gt(const T (&m)[6], T (&o)[3])
     {
-        const f32x4 s12 = m[1] + m[2], s34 = m[3] + m[4];
+        const T s12 = m[1] + m[2], s34 = m[3] + m[4];
         o[0] = 0.25f * m[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
         o[1] = (1.f / 6.f) * (m[2] - m[1]) + (1.f / 12.f) * (m[3] - m[4]);
         o[2] = (1.f / 6.f) * (s34 - s12) + m[5];
@@ -200,30 +245,31 @@ struct WinoGeom {
     int B, H, W, Th, Tw, T;   // image, tiles per column / row, tiles in total
 };
 
-// V[g][t][c] = (B^T d B)[g]; one thread per (tile, channel quad), channel quad fastest
-template <int F, int NT>
+// V[g][t][c] = (B^T d B)[g]; one thread per (tile, VW channels), channels fastest
+template <int F, int NT, int VW>
 __global__ __launch_bounds__(NT) void wino_input_kernel(const GSrc S, const WinoGeom G,
                                                         float *__restrict__ V)
 {
     constexpr int NA = Wino<F>::NA;
-    const int c4n = S.C >> 2;
+    typedef typename Vec<VW>::T T;
+    const int cn = S.C / VW;
     const long long idx = (long long)blockIdx.x * NT + threadIdx.x;
-    if (idx >= (long long)G.T * c4n) return;
-    const int t = (int)(idx / c4n), c = (int)(idx - (long long)t * c4n) * 4;
+    if (idx >= (long long)G.T * cn) return;
+    const int t = (int)(idx / cn), c = (int)(idx - (long long)t * cn) * VW;
     const int tx = t % G.Tw, r = t / G.Tw, ty = r % G.Th, b = r / G.Th;
     const float *base = S.p + (size_t)b * S.sb + c;
-    f32x4 u[NA][NA];
+    T u[NA][NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {   // column j of the patch: u[.][j] = B^T d[.][j]
         const int x = F * tx - 1 + j;
-        f32x4 d[NA];
+        T d[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int y = F * ty - 1 + i;
             const bool ok = ((unsigned)y < (unsigned)G.H) & ((unsigned)x < (unsigned)G.W);
-            d[i] = ok ? ld4(base + (size_t)y * S.sy + (size_t)x * S.sx) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[i] = ok ? Vec<VW>::ld(base + (size_t)y * S.sy + (size_t)x * S.sx) : Vec<VW>::zero();
         }
-        f32x4 o[NA];
+        T o[NA];
         Wino<F>::bt(d, o);
 #pragma unroll
         for (int i = 0; i < NA; ++i) u[i][j] = o[i];
@@ -232,10 +278,10 @@ __global__ __launch_bounds__(NT) void wino_input_kernel(const GSrc S, const Wino
     float *o = V + (size_t)t * S.C + c;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {   // V[i][.] = u[i][.] B
-        f32x4 v[NA];
+        T v[NA];
         Wino<F>::bt(u[i], v);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) st4(o + (size_t)(i * NA + j) * plane, v[j]);
+        for (int j = 0; j < NA; ++j) Vec<VW>::st(o + (size_t)(i * NA + j) * plane, v[j]);
     }
 }
 
@@ -246,36 +292,37 @@ struct WinoOut {
     int act, bwd_act, N;
 };
 
-// y[b][F ty + i][F tx + j][n] = epilogue((A^T m A)[i][j]); one thread per (tile, channel quad)
-template <int F, int NT>
+// y[b][F ty + i][F tx + j][n] = epilogue((A^T m A)[i][j]); one thread per (tile, VW channels)
+template <int F, int NT, int VW>
 __global__ __launch_bounds__(NT) void wino_output_kernel(const float *__restrict__ Mb, const WinoOut O,
                                                          const WinoGeom G)
 {
     constexpr int NA = Wino<F>::NA;
-    const int n4n = O.N >> 2;
+    typedef typename Vec<VW>::T T;
+    const int nn = O.N / VW;
     const long long idx = (long long)blockIdx.x * NT + threadIdx.x;
-    if (idx >= (long long)G.T * n4n) return;
-    const int t = (int)(idx / n4n), n = (int)(idx - (long long)t * n4n) * 4;
+    if (idx >= (long long)G.T * nn) return;
+    const int t = (int)(idx / nn), n = (int)(idx - (long long)t * nn) * VW;
     const int tx = t % G.Tw, r = t / G.Tw, ty = r % G.Th, b = r / G.Th;
     const size_t plane = (size_t)G.T * O.N;
     const float *mp = Mb + (size_t)t * O.N + n;
-    f32x4 s[F][NA];
+    T s[F][NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {   // s[.][j] = A^T m[.][j]
-        f32x4 m[NA];
+        T m[NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) m[i] = ld4(mp + (size_t)(i * NA + j) * plane);
-        f32x4 o[F];
+        for (int i = 0; i < NA; ++i) m[i] = Vec<VW>::ld(mp + (size_t)(i * NA + j) * plane);
+        T o[F];
         Wino<F>::at(m, o);
 #pragma unroll
         for (int i = 0; i < F; ++i) s[i][j] = o[i];
     }
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (O.bias) bv = ld4(O.bias + n);
+    T bv = Vec<VW>::zero();
+    if (O.bias) bv = Vec<VW>::ld(O.bias + n);
     const size_t o0 = (size_t)b * O.D.sb + (size_t)(F * ty) * O.D.sy + (size_t)(F * tx) * O.D.sx + n;
 #pragma unroll
     for (int i = 0; i < F; ++i) {   // one output row at a time: loads, then stores
-        f32x4 v[F];
+        T v[F];
         Wino<F>::at(s[i], v);
         size_t o[F];
 #pragma unroll
@@ -283,56 +330,50 @@ __global__ __launch_bounds__(NT) void wino_output_kernel(const float *__restrict
             o[j] = o0 + (size_t)i * O.D.sy + (size_t)j * O.D.sx;
             v[j] += bv;
         }
-        f32x4 a1[F], a2[F], as[F];
+        T a1[F], a2[F], as[F];
         if (O.D.addend)
 #pragma unroll
-            for (int j = 0; j < F; ++j) a1[j] = ld4(O.D.addend + o[j]);
+            for (int j = 0; j < F; ++j) a1[j] = Vec<VW>::ld(O.D.addend + o[j]);
         if (O.D.addend2)
 #pragma unroll
-            for (int j = 0; j < F; ++j) a2[j] = ld4(O.D.addend2 + o[j]);
+            for (int j = 0; j < F; ++j) a2[j] = Vec<VW>::ld(O.D.addend2 + o[j]);
         if (O.D.actsrc)
 #pragma unroll
-            for (int j = 0; j < F; ++j) as[j] = ld4(O.D.actsrc + o[j]);
+            for (int j = 0; j < F; ++j) as[j] = Vec<VW>::ld(O.D.actsrc + o[j]);
 #pragma unroll
         for (int j = 0; j < F; ++j) {
             if (O.D.addend) v[j] += a1[j];
             if (O.D.addend2) v[j] += a2[j];
-            if (O.D.actsrc)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[j][e] *= act_bwd(as[j][e], O.bwd_act);
+            if (O.D.actsrc) v[j] *= Vec<VW>::actb(as[j], O.bwd_act);
         }
         if (O.zout)
 #pragma unroll
-            for (int j = 0; j < F; ++j) st4(O.zout + o[j], v[j]);
+            for (int j = 0; j < F; ++j) Vec<VW>::st(O.zout + o[j], v[j]);
 #pragma unroll
-        for (int j = 0; j < F; ++j) {
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = act_fwd(v[j][e], O.act);
-            st4(O.D.p + o[j], y);
-        }
+        for (int j = 0; j < F; ++j) Vec<VW>::st(O.D.p + o[j], Vec<VW>::actf(v[j], O.act));
     }
 }
 
 // Z[g][t][n] = (A dY A^T)[g], dY = the tile's F x F output gradients (dense NHWC gout)
-template <int F, int NT>
+template <int F, int NT, int VW>
 __global__ __launch_bounds__(NT) void wino_gout_kernel(const float *__restrict__ gout, const WinoGeom G,
                                                        int N, float *__restrict__ Z)
 {
     constexpr int NA = Wino<F>::NA;
-    const int n4n = N >> 2;
+    typedef typename Vec<VW>::T T;
+    const int nn = N / VW;
     const long long idx = (long long)blockIdx.x * NT + threadIdx.x;
-    if (idx >= (long long)G.T * n4n) return;
-    const int t = (int)(idx / n4n), n = (int)(idx - (long long)t * n4n) * 4;
+    if (idx >= (long long)G.T * nn) return;
+    const int t = (int)(idx / nn), n = (int)(idx - (long long)t * nn) * VW;
     const int tx = t % G.Tw, r = t / G.Tw, ty = r % G.Th, b = r / G.Th;
     const float *p = gout + (((size_t)b * G.H + F * ty) * G.W + F * tx) * N + n;
-    f32x4 u[NA][F];
+    T u[NA][F];
 #pragma unroll
     for (int j = 0; j < F; ++j) {   // u[.][j] = A dY[.][j]
-        f32x4 d[F];
+        T d[F];
 #pragma unroll
-        for (int i = 0; i < F; ++i) d[i] = ld4(p + ((size_t)i * G.W + j) * N);
-        f32x4 o[NA];
+        for (int i = 0; i < F; ++i) d[i] = Vec<VW>::ld(p + ((size_t)i * G.W + j) * N);
+        T o[NA];
         Wino<F>::a(d, o);
 #pragma unroll
         for (int i = 0; i < NA; ++i) u[i][j] = o[i];
@@ -341,10 +382,10 @@ __global__ __launch_bounds__(NT) void wino_gout_kernel(const float *__restrict__
     float *o = Z + (size_t)t * N + n;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        f32x4 v[NA];
+        T v[NA];
         Wino<F>::a(u[i], v);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) st4(o + (size_t)(i * NA + j) * plane, v[j]);
+        for (int j = 0; j < NA; ++j) Vec<VW>::st(o + (size_t)(i * NA + j) * plane, v[j]);
     }
 }
 
@@ -408,48 +449,57 @@ inline unsigned nblocks(long long n, int nt) { return (unsigned)((n + nt - 1) / 
 }  // namespace
 
 // Output tile side of the forward / data-gradient evaluation: 4 when the image
-// allows it (DVSOF_WINO_F=2 forces the 2x2 form).
+// allows it (DVSOF_WINO_F=2 forces the 2x2 form), 0 = direct kernel.
+// The tile count is the row dimension of the component GEMMs and the
+// transformed weights are 4x (1.8x) the raw ones: with few tiles the layer is
+// bound by reading them.  Measured, batch 1 at 16x16 (16 | 64 tiles): whole
+// forward pass 1.88 | 1.63 ms against 0.75 ms direct; batch 8 (128 tiles): 52 us
+// per layer against 87 us direct.
 // The bf16x3 operand mode (mfma = 2, ~2^-16 per product) stays with the 2x2
 // form: the 4x4 transforms amplify the product error past its 1e-4 test bound.
-int wino_tile(int H, int W, int mfma)
+int wino_tile(int B, int H, int W, int mfma)
 {
     static const int f_env = env_int("DVSOF_WINO_F", 0);
-    if (f_env == 2 || mfma != 0) return 2;
-    return ((H % 4) == 0 && (W % 4) == 0) ? 4 : 2;
+    if ((H & 1) || (W & 1)) return 0;
+    const long long t4 = (long long)B * (H / 4) * (W / 4), t2 = (long long)B * (H / 2) * (W / 2);
+    if (f_env != 2 && mfma == 0 && (H % 4) == 0 && (W % 4) == 0 && t4 >= 64) return 4;
+    return t2 >= 128 ? 2 : 0;
 }
 
-int wino_components(int H, int W, int mfma)
+int wino_components(int B, int H, int W, int mfma)
 {
-    const int f = wino_tile(H, W, mfma);
+    const int f = wino_tile(B, H, W, mfma);
     return (f + 2) * (f + 2);
 }
 
 // A 3x3 / stride-1 / pad-1 problem over one dense NHWC source whose channel
 // counts make the transforms' memory traffic (~32 (C + N) bytes per output pixel
 // for the 2x2 form) cheaper than the matrix work they save: C N / (C + N) > ~100.
-bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int H, int W, int ksize, int stride,
-                         int pad, int upsample, int mfma)
+bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int B, int H, int W, int ksize,
+                         int stride, int pad, int upsample, int mfma)
 {
     static const bool off = getenv("DVSOF_NO_WINOGRAD") != nullptr;
     if (off) return false;
     if (nsrc != 1 || !layout_nhwc || upsample || ksize != 3 || stride != 1 || pad != 1) return false;
     if (mfma == 1) return false;   // bf16-rounded operands: the transforms amplify the rounding
-    if ((C % 64) || (N % 64) || (H & 1) || (W & 1)) return false;
-    return C >= 256 && N >= 256;
+    if ((C % 64) || (N % 64) || C < 256 || N < 256) return false;
+    return wino_tile(B, H, W, mfma == 2 ? 2 : 0) != 0;
 }
 
 size_t wino_scratch_floats(int B, int H, int W, int C, int N, int mfma)
 {
-    const int f = wino_tile(H, W, mfma);
+    const int f = wino_tile(B, H, W, mfma);
+    if (f == 0) return 0;
     return (size_t)(f + 2) * (f + 2) * B * (H / f) * (W / f) * ((size_t)C + N);
 }
 
 // U (forward form) and / or Ut (data-gradient form) from the raw weights
-int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int H, int W, int mfma,
+int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int B, int H, int W, int mfma,
                  hipStream_t st)
 {
     if (!weight) return DVSOF_EINVAL;
-    const int f = wino_tile(H, W, mfma);
+    const int f = wino_tile(B, H, W, mfma);
+    if (f == 0) return DVSOF_EINVAL;
     const unsigned nb = nblocks((long long)N * (C / 4), 256);
     if (U) {
         if (f == 4) hipLaunchKernelGGL((wino_weight_kernel<4, false>), dim3(nb), dim3(256), 0, st, weight, U, N, C);
@@ -468,13 +518,20 @@ template <int F>
 static int wino_launch_f(const GConvParams &P, float *scratch, hipStream_t st)
 {
     constexpr int NA = Wino<F>::NA, NG = NA * NA;
-    constexpr int NT = F == 4 ? 64 : 256;   // the 4x4 form has 4x fewer threads: smaller workgroups
+    constexpr int NT = 256;
     const int C = P.Cin_tot, N = P.N;
     WinoGeom G = {P.B, P.Hv, P.Wv, P.Hv / F, P.Wv / F, P.B * (P.Hv / F) * (P.Wv / F)};
     float *V = scratch, *Mb = scratch + (size_t)NG * G.T * C;
 
-    hipLaunchKernelGGL((wino_input_kernel<F, NT>), dim3(nblocks((long long)G.T * (C / 4), NT)), dim3(NT), 0,
-                       st, P.src[0], G, V);
+    // few tiles: one channel per thread (4x the threads; these launches are latency bound)
+    static const int vw_env = env_int("DVSOF_WINO_VW", 0);
+    const bool scalar = vw_env ? vw_env == 1 : (long long)G.T * (C > N ? C : N) / 4 < 256 * 256;
+    if (scalar)
+        hipLaunchKernelGGL((wino_input_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * C, NT)), dim3(NT), 0,
+                           st, P.src[0], G, V);
+    else
+        hipLaunchKernelGGL((wino_input_kernel<F, NT, 4>), dim3(nblocks((long long)G.T * (C / 4), NT)),
+                           dim3(NT), 0, st, P.src[0], G, V);
     DVSOF_LAUNCH_CHECK();
 
     GConvParams Q = {};
@@ -511,8 +568,12 @@ static int wino_launch_f(const GConvParams &P, float *scratch, hipStream_t st)
     if (rc) return rc;
 
     WinoOut O = {P.dst[0], P.bias, P.zout, P.act, P.bwd_act, N};
-    hipLaunchKernelGGL((wino_output_kernel<F, NT>), dim3(nblocks((long long)G.T * (N / 4), NT)), dim3(NT), 0,
-                       st, (const float *)Mb, O, G);
+    if (scalar)
+        hipLaunchKernelGGL((wino_output_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * N, NT)), dim3(NT), 0,
+                           st, (const float *)Mb, O, G);
+    else
+        hipLaunchKernelGGL((wino_output_kernel<F, NT, 4>), dim3(nblocks((long long)G.T * (N / 4), NT)),
+                           dim3(NT), 0, st, (const float *)Mb, O, G);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
@@ -527,7 +588,9 @@ int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hip
         return DVSOF_EINVAL;
     if (!scratch || scratch_floats < wino_scratch_floats(P.B, P.Hv, P.Wv, C, N, P.mfma_bf16))
         return DVSOF_ENOSPACE;
-    return wino_tile(P.Hv, P.Wv, P.mfma_bf16) == 4 ? wino_launch_f<4>(P, scratch, st) : wino_launch_f<2>(P, scratch, st);
+    const int f = wino_tile(P.B, P.Hv, P.Wv, P.mfma_bf16);
+    if (f == 0) return DVSOF_EINVAL;
+    return f == 4 ? wino_launch_f<4>(P, scratch, st) : wino_launch_f<2>(P, scratch, st);
 }
 
 // ---- weight gradient
@@ -573,21 +636,34 @@ size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N, int mfma)
 }
 
 template <int F>
-static int wino_wgrad_f(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
-                        int C, int N, int mfma_bf16, float *ws, hipStream_t st)
+static int wino_wgrad_f(const GSrc &X, const float *V_in, const float *gout, float *dW, float *dbias,
+                        int B, int H, int W, int C, int N, int mfma_bf16, float *ws, hipStream_t st)
 {
     constexpr int NA = Wino<F>::NA, NG = NA * NA;
-    constexpr int NT = F == 4 ? 64 : 256;
+    constexpr int NT = 256;
     WinoGeom G = {B, H, W, H / F, W / F, B * (H / F) * (W / F)};
     const int S = wino_wgrad_splits(NG, G.T, N, C);
-    float *V = ws, *Z = V + (size_t)NG * G.T * C, *dU = Z + (size_t)NG * G.T * N;
+    float *Vws = ws, *Z = Vws + (size_t)NG * G.T * C, *dU = Z + (size_t)NG * G.T * N;
     float *bias_part = dU + (size_t)NG * S * N * C;
+    const float *V = V_in ? V_in : Vws;   // V_in: the forward pass already transformed this input
 
-    hipLaunchKernelGGL((wino_input_kernel<F, NT>), dim3(nblocks((long long)G.T * (C / 4), NT)), dim3(NT), 0,
-                       st, X, G, V);
-    DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((wino_gout_kernel<F, NT>), dim3(nblocks((long long)G.T * (N / 4), NT)), dim3(NT), 0,
-                       st, gout, G, N, Z);
+    static const int vw_env = env_int("DVSOF_WINO_VW", 0);
+    const bool scalar = vw_env ? vw_env == 1 : (long long)G.T * (C > N ? C : N) / 4 < 256 * 256;
+    if (scalar) {
+        if (!V_in)
+            hipLaunchKernelGGL((wino_input_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * C, NT)), dim3(NT),
+                               0, st, X, G, Vws);
+        DVSOF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((wino_gout_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * N, NT)), dim3(NT), 0,
+                           st, gout, G, N, Z);
+    } else {
+        if (!V_in)
+            hipLaunchKernelGGL((wino_input_kernel<F, NT, 4>), dim3(nblocks((long long)G.T * (C / 4), NT)),
+                               dim3(NT), 0, st, X, G, Vws);
+        DVSOF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((wino_gout_kernel<F, NT, 4>), dim3(nblocks((long long)G.T * (N / 4), NT)),
+                           dim3(NT), 0, st, gout, G, N, Z);
+    }
     DVSOF_LAUNCH_CHECK();
 
     WGradParams Q = {};
@@ -634,13 +710,14 @@ static int wino_wgrad_f(const GSrc &X, const float *gout, float *dW, float *dbia
     return DVSOF_OK;
 }
 
-int wino_wgrad_launch(const GSrc &X, const float *gout, float *dW, float *dbias, int B, int H, int W,
-                      int C, int N, int mfma_bf16, float *ws, size_t ws_floats, hipStream_t st)
+int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *gout, float *dW, float *dbias, int B,
+                      int H, int W, int C, int N, int mfma_bf16, float *ws, size_t ws_floats,
+                      hipStream_t st)
 {
     if (X.flat || X.sc != 1 || X.C != C) return DVSOF_EINVAL;
     const int f = wino_wgrad_tile(B, H, W, mfma_bf16);
     if (f == 0) return DVSOF_EINVAL;
     if (!ws || ws_floats < wino_wgrad_workspace_floats(B, H, W, C, N, mfma_bf16)) return DVSOF_ENOSPACE;
-    return f == 4 ? wino_wgrad_f<4>(X, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st)
-                  : wino_wgrad_f<2>(X, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st);
+    return f == 4 ? wino_wgrad_f<4>(X, V_in, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st)
+                  : wino_wgrad_f<2>(X, V_in, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st);
 }

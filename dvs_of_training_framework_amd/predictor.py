@@ -123,7 +123,8 @@ class _PredictorFn(torch.autograd.Function):
                                         phase_weights=w_fwd)
             else:
                 w_fwd, w_dg = C.prepare(d, _phys(wgt), need_dg)
-            y, z = C.conv_fwd(d, w_fwd, bias, dev, residual, mish)
+            y, z = C.conv_fwd(d, w_fwd, bias, dev, residual, mish,
+                              keep_input_transform=want_grad)
             L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg))
             return y
 

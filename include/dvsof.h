@@ -268,6 +268,12 @@ typedef struct {
     size_t scratch_bytes; /* F(2x2,3x3) (dvsof_conv2d_scratch_bytes > 0); read by
                              dvsof_conv2d_fwd / _dgrad only, which return
                              DVSOF_ENOSPACE when it is missing or too small */
+    const float *winograd_input; /* optional, read by dvsof_conv2d_wgrad only:
+                             dvsof_conv2d_fwd leaves the transformed input of a
+                             Winograd layer at the start of `scratch`; a caller
+                             that kept that buffer intact passes it here and the
+                             weight gradient skips its own input transform
+                             (used when both run the same tile form) */
 } dvsof_conv_desc_t;
 
 /*
@@ -286,6 +292,9 @@ typedef struct {
  * same transforms inside its ordinary workspace.
  */
 size_t dvsof_conv2d_scratch_bytes(const dvsof_conv_desc_t *desc);
+/* 0: direct implicit GEMM; 2 | 4: Winograd output tile side used for this
+ * problem (kind 0 forward, 1 data gradient, 2 weight gradient); for tools. */
+int dvsof_conv2d_winograd_tile(const dvsof_conv_desc_t *desc, int kind);
 
 /*
  * Prepared weights.  An upsampled 3x3/pad-1 layer is evaluated as four 2x2

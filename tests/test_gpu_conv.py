@@ -41,13 +41,18 @@ CASES = [
     dict(B=2, H=9, W=7, src=[(20, 'nhwc')], Cout=48, stride=1, k=5, pad=2),
     dict(B=2, H=16, W=16, src=[(64, 'nhwc'), (64, 'nhwc'), (2, 'nchw')], Cout=32,
          up=True, act='mish'),
-    # wide 3x3 stride-1 layers: Winograd F(2x2,3x3) forward and data gradient
-    dict(B=2, H=8, W=6, src=[(256, 'nhwc')], Cout=320, stride=1, residual=True, wino=True),
-    dict(B=1, H=4, W=4, src=[(320, 'nhwc')], Cout=256, stride=1, act='mish', wino=True),
-    # ... and weight gradient (tile count a multiple of 16)
-    dict(B=3, H=8, W=16, src=[(256, 'nhwc')], Cout=384, stride=1, wino=True),
-    # >= 128 4x4 tiles: the weight gradient takes the F(4x4,3x3) form too
+    # wide 3x3 stride-1 layers with enough tiles: Winograd.  F(2x2,3x3) (W % 4 != 0),
+    # forward, data and weight gradient
+    dict(B=4, H=8, W=18, src=[(256, 'nhwc')], Cout=320, stride=1, residual=True, wino=True),
+    # F(4x4,3x3) forward / data gradient (64 tiles), F(2x2) weight gradient
+    dict(B=8, H=8, W=16, src=[(320, 'nhwc')], Cout=256, stride=1, act='mish', wino=True),
+    # fewer than 64 4x4 tiles: the 2x2 form on a 4-aligned image
+    dict(B=6, H=8, W=16, src=[(256, 'nhwc')], Cout=384, stride=1, wino=True),
+    # >= 128 4x4 tiles: the weight gradient takes the F(4x4,3x3) form too and
+    # reuses the forward's transformed input
     dict(B=8, H=16, W=16, src=[(256, 'nhwc')], Cout=256, stride=1, wino=True),
+    # too few tiles: the direct kernel (transformed weights would dominate)
+    dict(B=1, H=8, W=8, src=[(256, 'nhwc')], Cout=256, stride=1),
 ]
 
 
@@ -115,8 +120,11 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     assert (nscratch > 0) == (bool(case.get('wino')) and mfma != 'bf16')
     w_dev = wphys(w.detach())
     w_fwd, wt = C.prepare(desc, w_dev, True)     # sub-pixel forms for up-layers
+    # (Winograd layers: the weight gradient below reuses the forward's transformed
+    # input when both run the same tile form -- the last case; the others recompute)
     y, z = C.conv_fwd(desc, w_fwd, b.cuda(), 'cuda',
-                      nhwc(res) if res is not None else None, want_z=True)
+                      nhwc(res) if res is not None else None, want_z=True,
+                      keep_input_transform=bool(case.get('wino')))
     close(from_nhwc(y), y_ref)
     close(from_nhwc(z), z_ref)
     # backward w.r.t. the pre-activation output
@@ -142,7 +150,7 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
 
 @pytest.mark.parametrize('case', [
     dict(B=2, H=8, W=8, src=[(32, 'nhwc')], Cout=64, stride=2),
-    dict(B=2, H=8, W=8, src=[(256, 'nhwc')], Cout=256, stride=1),     # Winograd
+    dict(B=8, H=16, W=8, src=[(256, 'nhwc')], Cout=256, stride=1),     # Winograd F(4x4,3x3)
 ])
 def test_dgrad_epilogue_addends_and_act(case):
     from dvs_of_training_framework_amd import conv as C
@@ -154,7 +162,7 @@ def test_dgrad_epilogue_addends_and_act(case):
     a1, a2 = torch.randn(x.shape), torch.randn(x.shape)
     ysrc = torch.randn(x.shape)
     want = (x.grad + a1 + a2) * (ysrc > 0).float()
-    buf = torch.empty(2, 8, 8, case['src'][0][0], device='cuda')
+    buf = torch.empty(case['B'], case['H'], case['W'], case['src'][0][0], device='cuda')
     _, wt = C.prepare(desc, wphys(w), True)
     C.conv_dgrad(desc, wt, nhwc(gz), [dict(p=buf, addend=nhwc(a1), addend2=nhwc(a2),
                                            actsrc=nhwc(ysrc))], C.ACT_RELU)
@@ -187,13 +195,15 @@ def test_flow_head(Cc, act):
     close(db, b.grad)
 
 
-@pytest.mark.parametrize('mish', [False, True])
-def test_predictor_vs_torch_reference(mish):
+@pytest.mark.parametrize('mish,shape', [(False, (2, 5, 32, 48)), (True, (2, 5, 32, 48)),
+                                        # residual stage 8 x 8 x 8: 128 2x2 tiles -> Winograd
+                                        (False, (8, 5, 128, 128))])
+def test_predictor_vs_torch_reference(mish, shape):
     """Whole predictor forward + backward (explicit schedule) vs ATen autograd."""
     from dvs_of_training_framework_amd.predictor import Predictor
     from oracle.ref_model import ref_predictor
     torch.manual_seed(1)
-    B, Cin, H, W = 2, 5, 32, 48
+    B, Cin, H, W = shape
     act = torch.nn.Mish() if mish else torch.nn.ReLU()
     net = Predictor(Cin, act)
     x = torch.randn(B, Cin, H, W)

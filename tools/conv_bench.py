@@ -34,6 +34,8 @@ def main():
     def wrap(fn, kind, name):
         def inner(desc, *args, **kw):
             tile = lib.dvsof_conv2d_tile_id(ctypes.byref(desc), kind)
+            wino = lib.dvsof_conv2d_winograd_tile(ctypes.byref(desc), kind)
+            tile = 40 + wino if wino else tile      # 42 / 44: Winograd F(2x2) / F(4x4)
             e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
             e0.record()
             out = fn(desc, *args, **kw)
