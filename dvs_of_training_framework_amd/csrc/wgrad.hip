@@ -275,14 +275,39 @@ __global__ __launch_bounds__(256) void colsum_scalar_kernel(const float *__restr
 
 // Tail workgroups of the reduce kernels: dbias[c] = sum_z bias_part[z][c]
 // (the per-slab column sums wgrad2 leaves behind), fixed order.
+// The 256 threads of a tail workgroup split into channel lanes x slab lanes: a
+// single thread per channel walked all nslab partials as one dependent chain
+// (27 us for 128 slabs x 32 channels, longer than the reduce it rides on).
 __device__ __forceinline__ void bias_tail(int blk, const float *__restrict__ bias_part, int nslab,
                                           int Cout, float *__restrict__ dbias)
 {
-    const int c = blk * 256 + threadIdx.x;
-    if (c >= Cout) return;
+    __shared__ float bred[256];
+    const int c0 = blk * 256;
+    const int G = Cout - c0 < 256 ? Cout - c0 : 256;     // channels of this workgroup
+    int gl = 1;
+    while (gl < G) gl <<= 1;                              // channel lanes (power of two <= 256)
+    const int RP = 256 / gl;                              // slab lanes
+    const int cl = threadIdx.x % gl, zl = threadIdx.x / gl;
     float a = 0.f;
-    for (int z = 0; z < nslab; ++z) a += bias_part[(size_t)z * Cout + c];
-    dbias[c] = a;
+    if (cl < G) {
+        const float *p = bias_part + c0 + cl;
+        int z = zl;
+        for (; z + 3 * RP < nslab; z += 4 * RP) {         // four loads in flight
+            const float v0 = p[(size_t)z * Cout], v1 = p[(size_t)(z + RP) * Cout];
+            const float v2 = p[(size_t)(z + 2 * RP) * Cout], v3 = p[(size_t)(z + 3 * RP) * Cout];
+            a += v0;
+            a += v1;
+            a += v2;
+            a += v3;
+        }
+        for (; z < nslab; z += RP) a += p[(size_t)z * Cout];
+    }
+    bred[threadIdx.x] = a;
+    __syncthreads();
+    if (zl == 0 && cl < G) {
+        for (int k = 1; k < RP; ++k) a += bred[k * gl + cl];   // fixed order
+        dbias[c0 + cl] = a;
+    }
 }
 
 // dbias[c] = sum_b part[b][c] over the colsum workgroups: one wave per channel,
