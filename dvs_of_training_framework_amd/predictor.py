@@ -104,20 +104,57 @@ class _PredictorFn(torch.autograd.Function):
         if side is not None:
             side.wait_stream(main)
 
+        # Prepared FORWARD forms (Winograd-domain weights of the residual
+        # layers, sub-pixel phase kernels of the decoder) are not needed
+        # before the encoder has run: when training they are made on the
+        # second stream too, ahead of the data-gradient forms, and the main
+        # stream waits for them once, at the first residual layer.
+        pre, pre_ready = {}, None
+        if side is not None:
+            h16, w16 = H // 16, W // 16
+            specs = [(4 + 2 * i + j, [(x0, 512, C.NHWC)], h16, w16, 512,
+                      res[i][2 * j], False)
+                     for i in range(NUM_RES) for j in range(2)]
+            cx_, hh, ww = 512, h16, w16
+            for i in range(4):
+                srcs_ = [(x0, cx_, C.NHWC), (x0, ENC_CH[3 - i], C.NHWC)]
+                if i > 0:
+                    srcs_.append((x0, 2, C.NCHW))
+                specs.append((4 + 2 * NUM_RES + i, srcs_, hh, ww, DEC_CH[i],
+                              dec[i][0], True))
+                cx_, hh, ww = DEC_CH[i], 2 * hh, 2 * ww
+            with torch.cuda.stream(side):
+                for li, srcs_, hh, ww, cout_, wgt_, up_ in specs:
+                    d_ = C.make_desc(srcs_, B, hh, ww, cout_, 3, 1, 1, up_, act,
+                                     module.mfma)
+                    w_f, _ = C.prepare(d_, _phys(wgt_), False)
+                    if w_f is not wgt_:
+                        pre[li] = w_f
+            pre_ready = torch.cuda.Event()
+            pre_ready.record(side)
+        waited = [False]
+
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
             d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act,
                             module.mfma)
-            # prepared weights: sub-pixel phase kernels for the decoder, and
-            # (when training) the data-gradient form, made once per step
+            # prepared weights: sub-pixel phase kernels for the decoder,
+            # Winograd forms for the residual layers, and (when training) the
+            # data-gradient form, made once per step
             first = len(L) == 0       # voxel input needs no data gradient
             need_dg = want_grad and not first
             if side is not None and need_dg:
-                w_fwd, _ = C.prepare(d, _phys(wgt), False)
-                if w_fwd is not wgt:          # phase kernels: made on main
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
+                if len(L) in pre:             # made on the second stream
+                    w_fwd = pre[len(L)]
+                    if not waited[0]:
+                        main.wait_event(pre_ready)
+                        waited[0] = True
+                else:
+                    w_fwd, _ = C.prepare(d, _phys(wgt), False)
+                    if w_fwd is not wgt:      # prepared form made on main
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        side.wait_event(ev)
                 with torch.cuda.stream(side):
                     _, w_dg = C.prepare(d, _phys(wgt), True,
                                         phase_weights=w_fwd)
