@@ -51,8 +51,8 @@ CASES = [
     # >= 128 4x4 tiles: the weight gradient takes the F(4x4,3x3) form too and
     # reuses the forward's transformed input
     dict(B=8, H=16, W=16, src=[(256, 'nhwc')], Cout=256, stride=1, wino=True),
-    # large up-sampling layer with a flow member: LDS-tiled flow-gradient rows (64-channel
-    # gout, two chunks) and the matrix-core flat-member weight gradient
+    # large up-sampling layer with a flow member: four-lanes-per-pixel flow-gradient rows
+    # and the matrix-core flat-member weight gradient
     dict(B=8, H=64, W=64, src=[(32, 'nhwc'), (32, 'nhwc'), (2, 'nchw')], Cout=64, up=True),
     # too few tiles: the direct kernel (transformed weights would dominate)
     dict(B=1, H=8, W=8, src=[(256, 'nhwc')], Cout=256, stride=1),
