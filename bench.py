@@ -46,8 +46,8 @@ def kernel_name(family, tile, gen, wino=0):
     if wino:
         # input / gradient transforms + NG component GEMMs + output transform
         ng = (wino + 2) ** 2
-        gemm = 'gconv2_kernel<2,2,1,1> 64x64' if family == 'gconv' else 'wgrad2_kernel<2,2,1,1> 64x64'
-        return f'winograd F({wino}x{wino},3x3) {family}: wino_*_kernel + {gemm} x{ng}'
+        gemm = 'gconv2_kernel<2,2,1,1,1,4,1,0,1>' if family == 'gconv' else 'wgrad2_kernel<2,2,1,1,0,1>'
+        return f'winograd F({wino}x{wino},3x3) {family}: wino_*_kernel + {gemm} 64x64 x{ng}'
     if gen == 0:
         return 'wgrad_flat_kernel (VALU, flat members)'
     # (gconv2 instantiations carry two more template arguments in rocprof
@@ -149,18 +149,20 @@ def executed_flops(desc, kind):
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC
-    passes (profiles/round1/h_traffic_pmc.csv, made by tools/pmc_traffic.py: FETCH_SIZE x2 for the gfx950
+    passes (profiles/round1/j_traffic_pmc.csv, made by tools/pmc_traffic.py: FETCH_SIZE x2 for the gfx950
     under-count + WRITE_SIZE, separate --pmc runs of tools/conv_bench.py on the
     same workload).  PMC cannot be collected from inside this process, so this
     is a recorded measurement, not a live one; None if the file is absent."""
     import csv
-    path = ROOT / 'profiles' / 'round1' / 'h_traffic_pmc.csv'
+    path = ROOT / 'profiles' / 'round1' / 'j_traffic_pmc.csv'
     if not path.exists():
         return None
     prefix = kernel.split('>')[0]          # e.g. gconv2_kernel<2,2,1,1
     num = den = 0.0
     with open(path) as f:
         for row in csv.DictReader(f):
+            if row['k'].endswith(',1>') and row['k'].count(',') in (8, 5):
+                continue        # TAG = 1 instantiations: Winograd component GEMMs
             if row['k'].startswith(prefix + ',') or row['k'] == prefix + '>':
                 n = float(row['n'])
                 num += n * (float(row['fetch_MB']) + float(row['write_MB'])) * 1e6
@@ -238,7 +240,7 @@ def measure_roofline(h, step_ms, steps=3):
             'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(fl / sec / 1e12 / peak, 4),
             'traffic': pmc_traffic(dom),
-            'traffic_source': 'profiles/round1/h_traffic_pmc.csv (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950; bytes/launch)',
+            'traffic_source': 'profiles/round1/j_traffic_pmc.csv (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950; bytes/launch)',
             'avg_launch_us': round(sec / n * 1e6, 2),
             # the dominant kernel with the second backward stream switched off
             # (no other kernel on the GPU): same launches, same inputs

@@ -42,7 +42,9 @@ struct KIt {
 // KSPLIT = 2: 8 waves; wave group g = wave/4 loads and multiplies sub-slice g of
 // every K-32 stage (two waves per SIMD even when the grid only offers one
 // workgroup per CU), the two accumulator sets are added through LDS at the end.
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, int BF16>
+// TAG only names the instantiation (1: the component GEMMs of winograd.hip, so
+// that profiles list them apart from the convolutions proper).
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, int BF16, int TAG = 0>
 __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvParams P,
                                                                  const int nflat, const int nvec_all)
 {
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, int BF16>
+template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT, int BF16, int TAG = 0>
 int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
@@ -494,12 +496,13 @@ int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
     constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * (sizeof(int) + sizeof(long long));
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, BF16>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        DVSOF_HIP_TRY(hipFuncSetAttribute(
+            (const void *)gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, BF16, TAG>,
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN, P.nph);
-    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, BF16>), grid,
+    hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, BF16, TAG>), grid,
                        dim3(CONV_NT * KSPLIT), LDS, st, P, nflat, nvec);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
@@ -566,6 +569,12 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
     }
     if (dbg & 2) nvec = nvec > 1 ? 1 : nvec;
     if (nflat > 0 || getenv("DVSOF_NO_PH_EXACT")) P.ph_exact = 0;
+    // Winograd component GEMMs (winograd.hip): 64 x 64, K depth 16 (measured best of the
+    // tiles / depths, tools/wino_sweep.sh), under their own kernel name
+    if (P.src_ph_stride != 0 && tile == 3 && !k32 && nflat == 0) {
+        if (P.mfma_bf16 == 2) return launch2x<2, 2, 1, 1, 1, 4, 1, 2, 1>(P, nflat, nvec, st);
+        if (P.mfma_bf16 == 0) return launch2x<2, 2, 1, 1, 1, 4, 1, 0, 1>(P, nflat, nvec, st);
+    }
     switch (tile) {
     case 1: return launch2<2, 2, 2, 2, 1, 4>(P, nflat, nvec, st);  // 128 x 128
     case 2: return k32 ? launch2<2, 2, 2, 1, 2, 3>(P, nflat, nvec, st)

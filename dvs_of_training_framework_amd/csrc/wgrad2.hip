@@ -20,7 +20,8 @@ constexpr int WNS = 4;  // ring stages
 constexpr unsigned WOOB = 0x80000000u;
 }  // namespace
 
-template <int WROWS, int WCOLS, int TM, int TN, int BF16>
+// TAG only names the instantiation (1: Winograd component GEMMs, see gconv2.hip)
+template <int WROWS, int WCOLS, int TM, int TN, int BF16, int TAG = 0>
 __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 
 namespace {
 
-template <int WROWS, int WCOLS, int TM, int TN, int BF16>
+template <int WROWS, int WCOLS, int TM, int TN, int BF16, int TAG = 0>
 int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
 {
     constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
@@ -309,12 +310,12 @@ int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
     constexpr size_t LDS = (size_t)WNS * (PA + PB) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16>,
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16, TAG>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid(ntiles, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
-    hipLaunchKernelGGL((wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16>), grid, dim3(CONV_NT), LDS, st, P);
+    hipLaunchKernelGGL((wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16, TAG>), grid, dim3(CONV_NT), LDS, st, P);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
@@ -347,6 +348,10 @@ bool wgrad2_eligible(const WGradParams &P)
 // for the tile width of `tile`.
 int wgrad2_launch(const WGradParams &P, int tile, int ntiles, hipStream_t st)
 {
+    if (P.src_ph_stride != 0 && tile == 3) {   // Winograd component GEMMs: own kernel name
+        if (P.mfma_bf16 == 2) return launch_w2x<2, 2, 1, 1, 2, 1>(P, ntiles, st);
+        if (P.mfma_bf16 == 0) return launch_w2x<2, 2, 1, 1, 0, 1>(P, ntiles, st);
+    }
     switch (tile) {
     case 1: return launch_w2<2, 2, 2, 2>(P, ntiles, st);  // 128 x 128
     case 2: return launch_w2<2, 2, 2, 1>(P, ntiles, st);  // 128 x 64
