@@ -24,7 +24,10 @@ def main():
     p = c.pivot_table(index=['Dispatch_Id', 'k'], columns='Counter_Name', values='Counter_Value',
                       aggfunc='sum')
     p['dur'] = c.groupby(['Dispatch_Id', 'k']).dur.first()
-    p = p.reset_index().sort_values('Dispatch_Id').tail(35)    # the conv launches of the last step
+    p = p.reset_index().sort_values('Dispatch_Id')
+    # the launches of the last step: from its first-layer kernel (the only gconv v1 launch) on
+    first = p.index[p.k.str.startswith('gconv_kernel<')]
+    p = p.loc[first[-1]:] if len(first) else p.tail(35)
     print('dispatch,k,dur_us,mfma_util,mfma_insts_M,valu_insts_M,wait_any,wait_inst,active_inst')
     for _, r in p.iterrows():
         util = r.SQ_VALU_MFMA_BUSY_CYCLES / (1024.0 * r.GRBM_GUI_ACTIVE / 8)
