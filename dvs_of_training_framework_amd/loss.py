@@ -101,6 +101,21 @@ class _LossTerms(torch.autograd.Function):
         return (None, None, None) + grads
 
 
+_UNIT = {}
+
+
+def unit_backward(loss):
+    """``loss.backward()`` with a cached device-resident 1.0 as the seed: the
+    fused loss recognises it (by address, no host sync) and hands out its flow
+    gradients without the x1.0 multi-tensor pass and without the ones_like
+    fill of every step."""
+    one = _UNIT.get(loss.device)
+    if one is None:
+        one = _UNIT[loss.device] = torch.ones((), dtype=loss.dtype,
+                                              device=loss.device)
+    torch.autograd.backward(loss, grad_tensors=one)
+
+
 class _FusedLoss(torch.autograd.Function):
     """loss = sum_t w_t * mean_k term[t,k] * scale with the flow gradients
     produced in the same sweep (dvsof_loss_fused).  ``images`` not None: the
@@ -140,6 +155,9 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_terms):
         if g_loss is None:
             return (None,) * (6 + len(ctx.grads))
+        one = _UNIT.get(g_loss.device)
+        if one is not None and g_loss.data_ptr() == one.data_ptr():
+            return (None,) * 6 + tuple(ctx.grads)      # seed is exactly 1.0
         # one multi-tensor launch for all scales
         return (None,) * 6 + tuple(torch._foreach_mul(list(ctx.grads), g_loss))
 

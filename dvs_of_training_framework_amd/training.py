@@ -14,6 +14,7 @@ What changed underneath:
 import torch
 
 from .common import mean
+from .loss import unit_backward
 from .timer import EventTimer, FakeTimer
 
 
@@ -158,9 +159,12 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
             optimizer.fused_active = is_step_boundary
         loss, (smoothness, photometric, out_reg), tags = process_minibatch(
             model, batch, timers, device, is_raw, evaluator, weights)
-        loss /= accumulation_steps
         timers('backprop').start()
-        loss.backward()
+        if accumulation_steps == 1:
+            unit_backward(loss)         # seed 1.0 without a fill / scaling pass
+        else:
+            loss /= accumulation_steps
+            loss.backward()
         timers('backprop').stop()
         if hasattr(model, 'strict'):
             model.strict = False    # layout was validated on the first batch

@@ -104,6 +104,33 @@ def test_training_step_vs_cpu_port(mish):
     assert list(tags) == ['4x6', '8x12', '16x24', '32x48']
 
 
+def test_unit_backward_equals_loss_backward():
+    """loss.unit_backward (cached device 1.0 seed recognised by the fused loss:
+    no ones_like fill, no x1.0 pass) gives bitwise the gradients of
+    loss.backward(); a scaled loss still goes through the scaling pass."""
+    from dvs_of_training_framework_amd.loss import init_losses, unit_backward
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch
+    B, H, W, C = 2, 32, 48, 5
+    model = make_model(C)
+    model.train()
+    ev = init_losses((H, W), B, model, DEV, sequence_length=1)
+    batch = synthetic.to_torch(synthetic.make_batch(5, B, H, W, 1500), DEV)
+
+    def grads(how):
+        for p in model.parameters():
+            p.grad = None
+        loss, _, _ = process_minibatch(model, batch, FakeTimer(), DEV, True, ev, [0.5, 1, 1])
+        how(loss)
+        return [p.grad.detach().clone() for p in model.parameters()]
+    ref = grads(lambda l: l.backward())
+    got = grads(unit_backward)
+    half = grads(lambda l: (l * 0.5).backward())
+    for a, b, c in zip(ref, got, half):
+        assert torch.equal(a, b)
+        assert torch.allclose(c, 0.5 * a, rtol=1e-5, atol=1e-9)
+
+
 def test_fused_adamw_matches_torch():
     from dvs_of_training_framework_amd.optim import FusedAdamW
     torch.manual_seed(3)
