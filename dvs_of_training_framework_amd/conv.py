@@ -85,11 +85,34 @@ def out_size(desc):
     return ho, wo
 
 
+_PLAN = {}
+
+
+def _plan(desc):
+    """Shape-only facts of a layer, cached: (raw weight elems, forward-form
+    elems, data-gradient-form elems, forward / data-gradient scratch bytes,
+    weight-gradient workspace bytes)."""
+    key = (desc.nsrc, tuple((desc.src[i].C, desc.src[i].layout)
+                            for i in range(desc.nsrc)), desc.B, desc.H, desc.W,
+           desc.upsample, desc.ksize, desc.stride, desc.pad, desc.Cout,
+           desc.mfma)
+    p = _PLAN.get(key)
+    if p is None:
+        lib, ref = _lib.lib(), ctypes.byref(desc)
+        raw = desc.Cout * desc.ksize ** 2 * sum(desc.src[i].C
+                                                for i in range(desc.nsrc))
+        p = _PLAN[key] = (raw, lib.dvsof_conv2d_fwd_weight_elems(ref),
+                          lib.dvsof_conv2d_dgrad_weight_elems(ref),
+                          lib.dvsof_conv2d_scratch_bytes(ref),
+                          lib.dvsof_conv2d_wgrad_workspace_bytes(ref))
+    return p
+
+
 def _scratch(desc, device):
     """Attach the scratch a Winograd-evaluated layer needs for this call
     (dvsof_conv2d_scratch_bytes; stream-ordered reuse by torch's allocator).
     -> the tensor, to be kept alive until the call is enqueued."""
-    n = _lib.lib().dvsof_conv2d_scratch_bytes(ctypes.byref(desc))
+    n = _plan(desc)[3]
     if n == 0:
         desc.scratch, desc.scratch_bytes = None, 0
         return None
@@ -122,22 +145,19 @@ def prepare(desc, weight, want_dgrad, phase_weights=None):
     ``phase_weights``: the w_fwd of an earlier call -- only the data-gradient
     form is made (from it, for a sub-pixel layer)."""
     lib = _lib.lib()
-    raw = desc.Cout * desc.ksize ** 2 * sum(desc.src[i].C
-                                            for i in range(desc.nsrc))
-    nf = lib.dvsof_conv2d_fwd_weight_elems(ctypes.byref(desc))
+    raw, nf, ndg, nscratch, _ = _plan(desc)
     dg_only = phase_weights is not None
     if dg_only:
         w_fwd = phase_weights
     else:
         w_fwd = weight if nf == raw else torch.empty(
             nf, dtype=torch.float32, device=weight.device)
-    w_dg = torch.empty(lib.dvsof_conv2d_dgrad_weight_elems(ctypes.byref(desc)),
-                       dtype=torch.float32, device=weight.device) \
+    w_dg = torch.empty(ndg, dtype=torch.float32, device=weight.device) \
         if want_dgrad else None
     make_fwd = not dg_only and nf != raw
     if make_fwd or want_dgrad:
         # Winograd layer: both forms come from the raw weights
-        wino = lib.dvsof_conv2d_scratch_bytes(ctypes.byref(desc)) > 0
+        wino = nscratch > 0
         # sub-pixel layer, dgrad only: weight = NULL, w_fwd = the phase kernels
         wp = None if (dg_only and nf != raw and not wino) else weight.data_ptr()
         fp = w_fwd.data_ptr() if (nf != raw) else None
@@ -173,7 +193,7 @@ def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE):
 
 
 def conv_wgrad(desc, gout, dweight, dbias):
-    nbytes = _lib.lib().dvsof_conv2d_wgrad_workspace_bytes(ctypes.byref(desc))
+    nbytes = _plan(desc)[4]
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32,
                      device=gout.device)
     kept = getattr(desc, '_wino_input', None)
