@@ -580,14 +580,16 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
     case 2: return k32 ? launch2<2, 2, 2, 1, 2, 3>(P, nflat, nvec, st)
                        : launch2<2, 2, 2, 1, 1, 4>(P, nflat, nvec, st);  // 128 x 64
     case 3: {
-        // <= 1 workgroup per CU: 8-wave form (two waves per SIMD from one workgroup)
+        // few workgroups per CU: 8-wave form (two waves per SIMD from one workgroup)
         static const bool no8 = getenv("DVSOF_GCONV_NO_KSPLIT") != nullptr;
         const long long blocks = ((P.M + 63) / 64) * ((P.N + 63) / 64) * P.nph;
         // ring depth 2 (64 KiB): a deeper ring is no faster stand-alone and its LDS
         // footprint keeps the second stream's workgroups off the CU
         if (k64 && !no8) return launch2<2, 2, 1, 1, 4, 2, 2>(P, nflat, nvec, st);
         if (k64) { /* 4-wave fallback keeps K32 counting */ return DVSOF_EINVAL; }
-        if (k32 && !no8 && nflat == 0 && blocks <= 256)
+        // (<= 2 workgroups per CU: measured +3 % on the 512-workgroup decoder layers over the 4-wave form)
+        static const long long ks_blocks = getenv("DVSOF_GCONV_KSPLIT_BLOCKS") ? atoll(getenv("DVSOF_GCONV_KSPLIT_BLOCKS")) : 512;
+        if (k32 && !no8 && nflat == 0 && blocks <= ks_blocks)
             return launch2<2, 2, 1, 1, 2, 4, 2>(P, nflat, nvec, st);
         return k32 ? launch2<2, 2, 1, 1, 2, 4>(P, nflat, nvec, st)
                    : launch2<2, 2, 1, 1, 1, 4>(P, nflat, nvec, st);  // 64 x 64
