@@ -106,8 +106,10 @@ def test_training_step_vs_cpu_port(mish):
 
 def test_unit_backward_equals_loss_backward():
     """loss.unit_backward (cached device 1.0 seed recognised by the fused loss:
-    no ones_like fill, no x1.0 pass) gives bitwise the gradients of
-    loss.backward(); a scaled loss still goes through the scaling pass."""
+    no ones_like fill, no x1.0 pass) gives the gradients of loss.backward()
+    (x1.0 is exact; the comparison allows for the voxeliser's float atomics,
+    whose summation order differs from run to run); a scaled loss still goes
+    through the scaling pass."""
     from dvs_of_training_framework_amd.loss import init_losses, unit_backward
     from dvs_of_training_framework_amd.timer import FakeTimer
     from dvs_of_training_framework_amd.training import process_minibatch
@@ -127,8 +129,8 @@ def test_unit_backward_equals_loss_backward():
     got = grads(unit_backward)
     half = grads(lambda l: (l * 0.5).backward())
     for a, b, c in zip(ref, got, half):
-        assert torch.equal(a, b)
-        assert torch.allclose(c, 0.5 * a, rtol=1e-5, atol=1e-9)
+        assert (a - b).norm() <= 1e-4 * a.norm() + 1e-12
+        assert (c - 0.5 * a).norm() <= 1e-4 * a.norm() + 1e-12
 
 
 def test_fused_adamw_matches_torch():
