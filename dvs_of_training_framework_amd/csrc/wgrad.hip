@@ -14,6 +14,7 @@
 // lane (consecutive lanes -> consecutive banks); at 64 cycles per MFMA the
 // reads are far off the critical path.
 #include "conv_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat);
@@ -794,7 +795,16 @@ int pick_tile_and_splits(const WGradParams &P, int *S_out)
     const int taps = P.ks * P.ks;
     static const int cand[5] = {1, 4, 3, 5, 2};
     static const int slots_of[6] = {0, 2, 3, 5, 3, 3};          // by tile id
-    static const double eff_of[6] = {0, 0.85, 0.80, 0.70, 0.80, 0.65};
+    // (64x64 is 2.6-3 % faster than 64x128 on the three wide decoder layers one at a time,
+    // tools/wgrad_sweep.sh, but beside the data-gradient stream the step then alternates
+    // between 2340 and 2470 samples/s from run to run; 64x128 gives a steady 2445)
+    static double eff_of[6] = {0, 0.85, 0.80, 0.70, 0.80, 0.65};
+    static bool eff_init = false;
+    if (!eff_init) {   // tuning: DVSOF_WGRAD_EFF="e1,e2,e3,e4,e5"
+        eff_init = true;
+        if (const char *e = getenv("DVSOF_WGRAD_EFF"))
+            sscanf(e, "%lf,%lf,%lf,%lf,%lf", &eff_of[1], &eff_of[2], &eff_of[3], &eff_of[4], &eff_of[5]);
+    }
     int best = -1, bestS = 1;
     double best_cost = 1e300;
     const long long ksteps = (P.M + BK - 1) / BK;
