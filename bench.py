@@ -71,11 +71,13 @@ def parse():
     p.add_argument('--dtype', choices=('f32', 'bf16', 'bf16x3'), default='f32',
                    help='conv matrix-core operand type (bf16: f32 storage and '
                         'accumulation, operands rounded in registers)')
-    p.add_argument('--fused-optimizer', action='store_true',
-                   help='update every gradient bucket during the backward '
-                        '(optim.fuse_into_backward) instead of in optimizer.step(); '
-                        'measured slower at B=8 (8 small updates beside the MFMA kernels '
-                        'vs one 78 us launch at the HBM roofline)')
+    p.add_argument('--fused-optimizer', nargs='?', const='coarse', default=None,
+                   choices=('coarse', 'buckets'),
+                   help='update parameters during the backward (optim.fuse_into_backward) '
+                        'instead of in optimizer.step(): "coarse" = decoder + residual '
+                        'parameters in one launch when their last weight gradient is done '
+                        '(beside the encoder backward), "buckets" = one launch per gradient '
+                        'bucket')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--cpu-samples', type=int, default=2)
@@ -96,7 +98,8 @@ class Harness:
         self.opt = FusedAdamW(self.model.predictor.parameters(), lr=1e-3,
                               weight_decay=1e-4, amsgrad=True)
         if getattr(a, 'fused_optimizer', False):
-            self.opt.fuse_into_backward(self.model.predictor)
+            self.opt.fuse_into_backward(self.model.predictor,
+                                        flush_at=None if a.fused_optimizer == 'buckets' else (5,))
         self.sched = torch.optim.lr_scheduler.LambdaLR(
             self.opt, lambda s: 2 ** (-s / 100000))
         self.losses = init_losses((a.height, a.width), a.batch, self.model,

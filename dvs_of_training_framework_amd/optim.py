@@ -83,14 +83,22 @@ class _FusedBase(torch.optim.Optimizer):
         self._launch(group, self._table(key, plist), steps.pop(), plist)
 
     # ---- update fused into the backward ------------------------------------
-    def fuse_into_backward(self, predictor):
-        """Update every gradient bucket of ``predictor`` as soon as its
+    def fuse_into_backward(self, predictor, flush_at=None):
+        """Update the gradient buckets of ``predictor`` as soon as their
         gradients are final (after the all-reduce under data parallelism)
         instead of in ``step()``: the HBM-bound update then runs beside the
         MFMA-bound backward kernels.  Same arithmetic, same result; ``step()``
         still has to be called and updates whatever is left.  Set
-        ``fused_active = False`` on micro-batches that only accumulate."""
+        ``fused_active = False`` on micro-batches that only accumulate.
+
+        flush_at: bucket indices at which everything collected so far is
+        updated in ONE launch (None: one launch per bucket).  ``(5,)`` updates
+        the decoder and residual parameters (82 % of the bytes) when the last
+        residual weight gradient is done, beside the encoder's backward, and
+        leaves the encoder buckets to ``step()``."""
         self.fused_active = True
+        self._flush_at = None if flush_at is None else set(flush_at)
+        self._pending = []
         self._done = set()
         self._group_of = {id(p): (gi, g) for gi, g in enumerate(self.param_groups)
                           for p in g['params']}
@@ -100,6 +108,11 @@ class _FusedBase(torch.optim.Optimizer):
     def _on_bucket(self, b, params):
         if not getattr(self, 'fused_active', False):
             return
+        if self._flush_at is not None:      # collect, update at the flush points
+            self._pending += params
+            if b not in self._flush_at:
+                return
+            params, self._pending = self._pending, []
         by_group = {}
         for p in params:
             if id(p) in self._group_of and p.grad is not None:
@@ -116,6 +129,8 @@ class _FusedBase(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         done = getattr(self, '_done', None)
+        if getattr(self, '_pending', None):
+            self._pending = []          # never flushed this step: step() takes them
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group['params'] if p.grad is not None and
                      not (done and id(p) in done)]

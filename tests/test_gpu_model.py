@@ -359,9 +359,11 @@ def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
     assert np.mean(losses[-5:]) < 0.97 * np.mean(losses[:5]), (losses[:5], losses[-5:])
 
 
+@pytest.mark.parametrize('flush_at', [None, (5,)])
 @pytest.mark.parametrize('opt_name', ['adamw', 'ranger'])
-def test_optimizer_fused_into_backward_is_the_same_update(opt_name):
-    """optim.fuse_into_backward: buckets are updated during the backward; the
+def test_optimizer_fused_into_backward_is_the_same_update(opt_name, flush_at):
+    """optim.fuse_into_backward: buckets are updated during the backward (one
+    launch per bucket, or everything up to a flush bucket in one launch); the
     weights after step() are bit-identical to the plain step()."""
     from dvs_of_training_framework_amd.optim import FusedAdamW, FusedRanger
     from dvs_of_training_framework_amd.predictor import Predictor
@@ -372,7 +374,7 @@ def test_optimizer_fused_into_backward_is_the_same_update(opt_name):
         opt = FusedAdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True) \
             if opt_name == 'adamw' else FusedRanger(net.parameters(), lr=1e-3)
         if fused:
-            opt.fuse_into_backward(net)
+            opt.fuse_into_backward(net, flush_at=flush_at)
         g = torch.Generator(device='cuda').manual_seed(3)
         for it in range(3):
             x = torch.randn(2, 5, 64, 64, device='cuda', generator=g)
