@@ -550,8 +550,12 @@ __global__ __launch_bounds__(256) void wgrad_flat_kernel(const FlatWG P, float *
 // waves per workgroup (a one-wave-per-workgroup version with UN pairs in
 // flight was latency bound: 49 us at the finest decoder stage).
 // NCB = ceil(ncol / 32) column blocks, NRB = 32-channel row blocks per pass.
+// with_bias: im2col column `ncol` is the constant 1, so output column ncol is the
+// column sum of gout = the bias gradient (free: the 32-wide MFMA block has idle
+// columns); partial rows then have ncol + 1 entries.
 template <int NCB, int NRB>
-__global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, float *__restrict__ part)
+__global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, float *__restrict__ part,
+                                                              const int with_bias)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int UN = 8, NW = 8;
@@ -559,6 +563,7 @@ __global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, fl
     const int lane = threadIdx.x & 63, li = lane & 31, lk = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ncol = P.ncol, C = P.S.C;
+    const int nout = ncol + (with_bias ? 1 : 0);      // output columns / partial row length
     // pixel pairs of this wave (contiguous range)
     const long long npair = ((long long)P.M + 1) / 2;
     const long long per = (npair + (long long)gridDim.x * NW - 1) / ((long long)gridDim.x * NW);
@@ -567,11 +572,12 @@ __global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, fl
     // per-lane column constants
     int cky[NCB], ckx[NCB];
     long long ccoff[NCB];
-    bool cok[NCB];
+    bool cok[NCB], cone[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         const int col = cb * 32 + li;
         cok[cb] = col < ncol;
+        cone[cb] = with_bias && col == ncol;
         const int tap = cok[cb] ? col / C : 0, c = col - tap * C;
         cky[cb] = tap / P.ks;
         ckx[cb] = tap - cky[cb] * P.ks;
@@ -611,7 +617,8 @@ __global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, fl
                     const bool ok = pok & cok[cb] & ((unsigned)Y < (unsigned)P.Hv) &
                                     ((unsigned)X < (unsigned)P.Wv);
                     const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
-                    bv[u][cb] = ok ? sb[(size_t)ys * P.S.sy + (size_t)xs * P.S.sx + ccoff[cb]] : 0.f;
+                    bv[u][cb] = ok ? sb[(size_t)ys * P.S.sy + (size_t)xs * P.S.sx + ccoff[cb]]
+                                   : (cone[cb] && pok) ? 1.f : 0.f;
                 }
                 pix += 2;
                 gp += 2 * (size_t)P.Cout;
@@ -665,8 +672,8 @@ __global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, fl
                             } else {
                                 const int col = cb * 32 + li;
                                 const int co = (rb0 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                                if (rb0 + a < nrb && col < ncol)
-                                    part[((size_t)blockIdx.x * P.Cout + co) * ncol + col] = v;
+                                if (rb0 + a < nrb && col < nout)
+                                    part[((size_t)blockIdx.x * P.Cout + co) * nout + col] = v;
                             }
                         }
             }
@@ -678,20 +685,26 @@ __global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, fl
 
 // dW[co][tap][coff + c] = sum_blocks part[blk][co][tap*C + c]; one wave per
 // output, lanes stride over the workgroups, shuffle tree (fixed order)
+// (nout = ncol + 1 with dbias: the last entry of a partial row is the bias gradient)
 __global__ __launch_bounds__(256) void wgrad_flat_reduce_kernel(const float *__restrict__ part,
                                                                 int nblocks, int Cout, int ncol,
                                                                 int C, int coff, int row_stride,
-                                                                int tap_stride, float *dW)
+                                                                int tap_stride, float *dW, int nout,
+                                                                float *dbias)
 {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= Cout * ncol) return;
-    const int co = i / ncol, col = i - co * ncol;
+    if (i >= Cout * nout) return;
+    const int co = i / nout, col = i - co * nout;
     float a = 0.f;
-    for (int b = lane; b < nblocks; b += 64) a += part[(size_t)b * Cout * ncol + i];
+    for (int b = lane; b < nblocks; b += 64) a += part[(size_t)b * Cout * nout + i];
     a = wave_sum(a);
     if (lane == 0) {
-        const int tap = col / C, c = col - tap * C;
-        dW[(size_t)co * row_stride + (size_t)tap * tap_stride + coff + c] = a;
+        if (col == ncol) {
+            dbias[co] = a;
+        } else {
+            const int tap = col / C, c = col - tap * C;
+            dW[(size_t)co * row_stride + (size_t)tap * tap_stride + coff + c] = a;
+        }
     }
 }
 
@@ -700,32 +713,43 @@ bool flat_ncol_ok(int ncol)
     return ncol == 18 || ncol == 27 || ncol == 45 || ncol == 81 || ncol == 108;
 }
 
-int flat_launch(const FlatWG &F, float *part, float *dW, hipStream_t st)
+// Does this flat member take the matrix-core kernel?
+// measured (batch 8): MFMA 33 vs VALU 46 us at M = 524288 / 18 columns, 39 vs 52 us at
+// M = 131072 / 45 columns; a tie at M = 131072 / 18 columns; VALU wins below
+bool flat_uses_mfma(const FlatWG &F)
+{
+    static const bool no_mfma = getenv("DVSOF_WGRAD_FLAT_VALU") != nullptr;
+    static const bool force_mfma = getenv("DVSOF_WGRAD_FLAT_MFMA") != nullptr;
+    const int ncb = (F.ncol + 31) / 32;
+    const bool big = F.M >= 262144 || (ncb == 2 && F.M >= 65536);
+    return !no_mfma && (big || force_mfma) && (F.Cout % 32) == 0 && ncb <= 2 && F.Wo >= 2;
+}
+
+// dbias != NULL (matrix-core kernel only, ncol % 32 != 0): the bias gradient comes out as
+// one more output column
+int flat_launch(const FlatWG &F, float *part, float *dW, float *dbias, hipStream_t st)
 {
     const long long nbl = ((long long)F.M + FLAT_PIX - 1) / FLAT_PIX;
     int nb = (int)(nbl < 512 ? (nbl < 1 ? 1 : nbl) : 512);   // VALU kernel: 64 pixels per round
-    static const bool no_mfma = getenv("DVSOF_WGRAD_FLAT_VALU") != nullptr;
     const int ncb = (F.ncol + 31) / 32, nrb = F.Cout / 32;
-    // measured (batch 8): MFMA 33 vs VALU 46 us at M = 524288 / 18 columns, 39 vs 52 us at
-    // M = 131072 / 45 columns; a tie at M = 131072 / 18 columns; VALU wins below
-    static const bool force_mfma = getenv("DVSOF_WGRAD_FLAT_MFMA") != nullptr;
-    const bool big = F.M >= 262144 || (ncb == 2 && F.M >= 65536);
-    if (!no_mfma && (big || force_mfma) && (F.Cout % 32) == 0 && ncb <= 2 && F.Wo >= 2) {
+    const int wb = dbias ? 1 : 0;
+    if (dbias && (!flat_uses_mfma(F) || (F.ncol % 32) == 0)) return DVSOF_EINVAL;
+    if (flat_uses_mfma(F)) {
         // 8 waves per workgroup, >= 32 pixel pairs per wave, at most 512 partial sums
         const long long npair = ((long long)F.M + 1) / 2;
         long long nw = npair / (32 * 8);
         nw = nw < 1 ? 1 : nw > 512 ? 512 : nw;
         nb = (int)nw;
         if (ncb == 1 && nrb >= 4)
-            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 4>), dim3(nb), dim3(512), 0, st, F, part);
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 4>), dim3(nb), dim3(512), 0, st, F, part, wb);
         else if (ncb == 1 && nrb >= 2)
-            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 2>), dim3(nb), dim3(512), 0, st, F, part);
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 2>), dim3(nb), dim3(512), 0, st, F, part, wb);
         else if (ncb == 1)
-            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 1>), dim3(nb), dim3(512), 0, st, F, part);
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<1, 1>), dim3(nb), dim3(512), 0, st, F, part, wb);
         else if (nrb >= 2)
-            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<2, 2>), dim3(nb), dim3(512), 0, st, F, part);
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<2, 2>), dim3(nb), dim3(512), 0, st, F, part, wb);
         else
-            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<2, 1>), dim3(nb), dim3(512), 0, st, F, part);
+            hipLaunchKernelGGL((wgrad_flat_mfma_kernel<2, 1>), dim3(nb), dim3(512), 0, st, F, part, wb);
     } else
     switch (F.ncol) {
     case 18: hipLaunchKernelGGL(wgrad_flat_kernel<18>, dim3(nb), dim3(256), 0, st, F, part); break;
@@ -737,9 +761,9 @@ int flat_launch(const FlatWG &F, float *part, float *dW, hipStream_t st)
     }
     DVSOF_LAUNCH_CHECK();
     const int taps = F.ks * F.ks;
-    hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3((F.Cout * F.ncol + 3) / 4), dim3(256), 0,
+    hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3((F.Cout * (F.ncol + wb) + 3) / 4), dim3(256), 0,
                        st, (const float *)part, nb, F.Cout, F.ncol, F.S.C, F.coff,
-                       taps * F.Cin_tot, F.Cin_tot, dW);
+                       taps * F.Cin_tot, F.Cin_tot, dW, F.ncol + wb, dbias);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
@@ -923,7 +947,11 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
         }
         if (rc) return rc;
     }
-    if (dbias && !bias_in_kernel) {  // column sums of gout (all phases cover gout exactly once)
+    // flat-only layer on the matrix-core flat kernel: the bias gradient is one more output
+    // column of that kernel (no pass over gout of its own)
+    const bool bias_by_flat = dbias && !bias_in_kernel && flat_valu && nflat >= 1 &&
+                              flat_uses_mfma(flat[0]) && (flat[0].ncol % 32) != 0;
+    if (dbias && !bias_in_kernel && !bias_by_flat) {  // column sums of gout (all phases cover gout exactly once)
         const long long rows = (long long)P.B * (P.g_sb / P.Cout);
         const int nb = colsum_blocks(rows);
         if (P.Cout & 3)
@@ -966,9 +994,9 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
     if (flat_valu) {   // overwrites the flat members' columns of dW
         float *part = bias_part + (dbias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
         for (int i = 0; i < nflat; ++i) {
-            rc = flat_launch(flat[i], part, dW, st);
+            rc = flat_launch(flat[i], part, dW, (i == 0 && bias_by_flat) ? dbias : nullptr, st);
             if (rc) return rc;
-            part += (size_t)FLAT_BLOCKS * flat[i].Cout * flat[i].ncol;
+            part += (size_t)FLAT_BLOCKS * flat[i].Cout * (flat[i].ncol + 1);
         }
     }
     return DVSOF_OK;
@@ -977,7 +1005,8 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
 size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat)
 {
     size_t n = 0;
-    for (int i = 0; i < nflat; ++i) n += (size_t)FLAT_BLOCKS * flat[i].Cout * flat[i].ncol;
+    // (+ 1: room for the bias column of the matrix-core kernel's partial rows)
+    for (int i = 0; i < nflat; ++i) n += (size_t)FLAT_BLOCKS * flat[i].Cout * (flat[i].ncol + 1);
     return n;
 }
 
