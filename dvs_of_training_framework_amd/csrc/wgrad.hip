@@ -602,6 +602,24 @@ __global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, fl
             bb = (int)(t / P.Ho);
         }
         const float *gp = P.gout + (size_t)pix * P.Cout + rb0 * 32 + li;
+        // Per-lane state of the output row the pixel is in: element offset of the source
+        // row each column reads and its validity -- recomputed on row changes only, so a
+        // step costs an add, a compare, a shift and one multiply-add per column.
+        long long ybase[NCB];
+        bool yok[NCB];
+        auto new_row = [&]() {
+            const int Y0 = oy * P.stride - P.pad;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int Y = Y0 + cky[cb];
+                yok[cb] = cok[cb] & ((unsigned)Y < (unsigned)P.Hv);
+                const int ys = P.up ? Y >> 1 : Y;
+                ybase[cb] = (long long)bb * P.S.sb + (long long)ys * P.S.sy + ccoff[cb];
+            }
+        };
+        new_row();
+        const int xstep = 2 * P.stride, sx = P.S.sx;
+        int X0 = ox * P.stride - P.pad;
         // UN pixel pairs: gout values and im2col values of this lane
         auto load_set = [&](float (&av)[UN][NRB], float (&bv)[UN][NCB]) {
 #pragma unroll
@@ -609,26 +627,26 @@ __global__ __launch_bounds__(512) void wgrad_flat_mfma_kernel(const FlatWG P, fl
                 const bool pok = (qn + u < q1) && (pix < P.M);
 #pragma unroll
                 for (int a = 0; a < NRB; ++a) av[u][a] = (pok && rb0 + a < nrb) ? gp[a * 32] : 0.f;
-                const int Y0 = oy * P.stride - P.pad, X0 = ox * P.stride - P.pad;
-                const float *sb = P.S.p + (size_t)bb * P.S.sb;
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
-                    const int Y = Y0 + cky[cb], X = X0 + ckx[cb];
-                    const bool ok = pok & cok[cb] & ((unsigned)Y < (unsigned)P.Hv) &
-                                    ((unsigned)X < (unsigned)P.Wv);
-                    const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
-                    bv[u][cb] = ok ? sb[(size_t)ys * P.S.sy + (size_t)xs * P.S.sx + ccoff[cb]]
+                    const int X = X0 + ckx[cb];
+                    const bool ok = pok & yok[cb] & ((unsigned)X < (unsigned)P.Wv);
+                    const int xs = P.up ? X >> 1 : X;
+                    bv[u][cb] = ok ? P.S.p[ybase[cb] + (long long)xs * sx]
                                    : (cone[cb] && pok) ? 1.f : 0.f;
                 }
                 pix += 2;
                 gp += 2 * (size_t)P.Cout;
                 ox += 2;
+                X0 += xstep;
                 if (ox >= P.Wo) {
                     ox -= P.Wo;
+                    X0 = ox * P.stride - P.pad;
                     if (++oy == P.Ho) {
                         oy = 0;
                         ++bb;
                     }
+                    new_row();
                 }
             }
             qn += UN;
@@ -735,9 +753,10 @@ int flat_launch(const FlatWG &F, float *part, float *dW, float *dbias, hipStream
     const int wb = dbias ? 1 : 0;
     if (dbias && (!flat_uses_mfma(F) || (F.ncol % 32) == 0)) return DVSOF_EINVAL;
     if (flat_uses_mfma(F)) {
-        // 8 waves per workgroup, >= 32 pixel pairs per wave, at most 512 partial sums
+        // 8 waves per workgroup, >= PPW pixel pairs per wave, at most 512 partial sums
+        static const int ppw = getenv("DVSOF_FLAT_PPW") ? atoi(getenv("DVSOF_FLAT_PPW")) : 32;
         const long long npair = ((long long)F.M + 1) / 2;
-        long long nw = npair / (32 * 8);
+        long long nw = npair / (ppw * 8);
         nw = nw < 1 ? 1 : nw > 512 ? 512 : nw;
         nb = (int)nw;
         if (ncb == 1 && nrb >= 4)
