@@ -110,7 +110,9 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t, const
 namespace {
 
 constexpr int VT = 32;            // tile edge (pixels)
-constexpr int EPT = 4;            // events per thread in pass 1
+// events per thread in pass 1: 4 up to ~2 M events, 8 above (measured: 24.0 vs 26.3 us at
+// 0.5 M events, 111 vs 108 us at 4.2 M, 137 vs 121 us at 4 M events on 512 x 512 x 12)
+constexpr int64_t EPT8_FROM = 1 << 21;
 constexpr int V2_MAX_TILES = 8192;
 
 struct VoxV2 {
@@ -136,6 +138,7 @@ struct VoxV2 {
     int64_t *lin0;
 };
 
+template <int EPT>
 __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
 {
     extern __shared__ int sh[];          // hist[ntile], base[ntile]
@@ -337,8 +340,12 @@ int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t, con
     P.out = out; P.bin0 = bin0; P.lin0 = lin0;
     // cursor[ntile] + ovf_count, rounded up to 64 B (one fill kernel, no tail)
     DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, (((size_t)P.ntile + 1) * 4 + 63) / 64 * 64, st));
-    const int nb = (int)((n + (int64_t)NT * EPT - 1) / ((int64_t)NT * EPT));
-    hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb), dim3(NT), (size_t)P.ntile * 8, st, P);
+    if (n >= EPT8_FROM)
+        hipLaunchKernelGGL(vox_bucket_kernel<8>, dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT),
+                           (size_t)P.ntile * 8, st, P);
+    else
+        hipLaunchKernelGGL(vox_bucket_kernel<4>, dim3((unsigned)((n + NT * 4 - 1) / (NT * 4))), dim3(NT),
+                           (size_t)P.ntile * 8, st, P);
     DVSOF_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), (size_t)C * VT * VT * 4, st, P);
     DVSOF_LAUNCH_CHECK();
@@ -384,8 +391,12 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
     P.out = out; P.bin0 = bin0; P.lin0 = lin0;
     // cursor[ntile] + ovf_count, rounded up to 64 B (one fill kernel, no tail)
     DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, (((size_t)P.ntile + 1) * 4 + 63) / 64 * 64, st));
-    const int nb = (int)((n + (int64_t)NT * EPT - 1) / ((int64_t)NT * EPT));
-    hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb), dim3(NT), (size_t)P.ntile * 8, st, P);
+    if (n >= EPT8_FROM)
+        hipLaunchKernelGGL(vox_bucket_kernel<8>, dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT),
+                           (size_t)P.ntile * 8, st, P);
+    else
+        hipLaunchKernelGGL(vox_bucket_kernel<4>, dim3((unsigned)((n + NT * 4 - 1) / (NT * 4))), dim3(NT),
+                           (size_t)P.ntile * 8, st, P);
     DVSOF_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), (size_t)C * VT * VT * 4, st, P);
     DVSOF_LAUNCH_CHECK();

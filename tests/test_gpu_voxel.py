@@ -36,19 +36,21 @@ def test_voxelize_vs_oracle(B, C, H, W, n):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-3, atol=2e-5)
 
 
-def test_voxel_mass_conservation_full_size():
-    """Config-5 scale input (1M events, 512x512x12): sum over bins of the grid
-    equals the polarity-signed count image (weights (1-f) + f = 1)."""
+@pytest.mark.parametrize('B,n', [(1, 1_000_000),
+                                 (3, 800_000)])    # 2.4 M events: the 8-events-per-thread pass
+def test_voxel_mass_conservation_full_size(B, n):
+    """Config-5 scale input (1M events per sample, 512x512x12): sum over bins of
+    the grid equals the polarity-signed count image (weights (1-f) + f = 1)."""
     from dvs_of_training_framework_amd.voxel import voxelize
-    B, C, H, W, n = 1, 12, 512, 512, 1_000_000
+    C, H, W = 12, 512, 512
     rng = np.random.default_rng(8)
     ev = synthetic.make_events(rng, B, H, W, n)
     d = dev_events(ev)
     t0 = torch.zeros(B, device='cuda')
     t1 = torch.full((B,), synthetic.WINDOW, device='cuda')
     grid = voxelize(d, t0, t1, B, C, H, W)
-    signed = torch.zeros(H * W, device='cuda')
-    signed.index_add_(0, d['y'] * W + d['x'], d['polarity'].float())
+    signed = torch.zeros(B * H * W, device='cuda')
+    signed.index_add_(0, (d['sample_index'] * H + d['y']) * W + d['x'], d['polarity'].float())
     err = (grid.sum(1).view(-1) - signed).abs().max()
     assert float(err) < 1e-3
 
