@@ -9,10 +9,29 @@ all-reduced (average) on a side HIP stream gated by an event, so the exchange
 overlaps the rest of the backward.  ``wait()`` makes the compute stream wait
 for the outstanding collectives right before the optimizer step.
 """
+import contextlib
 import os
+import sys
 
 import torch
 import torch.distributed as dist
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a five-line version banner on STDOUT when rank 0 creates its
+    first communicator; a caller that parses this process's stdout (one JSON
+    line from bench.py) must not see it.  File-descriptor level: the banner
+    comes from C code."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def init_distributed(device_type='cuda'):
@@ -28,8 +47,12 @@ def init_distributed(device_type='cuda'):
         backend = 'nccl' if device_type == 'cuda' else 'gloo'
         if device_type == 'cuda':
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local))
+            with _stdout_to_stderr():
+                dist.init_process_group(backend, rank=rank, world_size=world,
+                                        device_id=torch.device('cuda', local))
+                # communicator creation (and its banner) happens here at the latest
+                dist.all_reduce(torch.zeros(1, device=torch.device('cuda', local)))
+                torch.cuda.synchronize()
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
