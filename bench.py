@@ -358,7 +358,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     out = None
     if rank == 0:
