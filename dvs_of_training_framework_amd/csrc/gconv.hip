@@ -444,8 +444,6 @@ __global__ __launch_bounds__(256) void gconv_flat_rows_quad_kernel(const GConvPa
 
 bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_bytes);
 int gconv2_launch(const GConvParams &P, int tile, hipStream_t st);
-bool gconv3_eligible(const GConvParams &P, int tile, long long max_src_bytes, long long w_bytes);
-int gconv3_launch(const GConvParams &P, int tile, hipStream_t st);
 
 // Internal entry (not part of the C ABI): picks the tile shape and launches.
 int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
@@ -499,9 +497,6 @@ int gconv_launch(const GConvParams &P, int tile_hint, hipStream_t st)
             src_bytes = b > src_bytes ? b : src_bytes;
         }
         const long long w_bytes = (long long)P.N * P.ks * P.ks * P.Cin_tot * 4 * P.nph;
-        static const bool no_v3 = getenv("DVSOF_GCONV_NO_V3") != nullptr;
-        if (!force_v1 && !no_v3 && gconv3_eligible(P, tile, src_bytes, w_bytes))
-            return gconv3_launch(P, tile, st);
         if (!force_v1 && gconv2_eligible(P, src_bytes, w_bytes)) return gconv2_launch(P, tile, st);
     }
     switch (tile) {

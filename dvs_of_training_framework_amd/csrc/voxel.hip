@@ -45,10 +45,14 @@ __global__ __launch_bounds__(NT) void voxelize_kernel(
                 const float tn = dt > 0.f ? ((ts - lo) / dt) * (float)(C - 1) : 0.f;
                 c0 = min((int)floorf(tn), C - 1);
                 const float f = tn - (float)c0;
-                const float p = (float)pol[i];
+                // polarity is a SIGN (VOXEL_SPEC): 0 contributes nothing, |p| > 1 counts once
+                const int64_t pv = pol[i];
+                const float p = pv > 0 ? 1.f : (pv < 0 ? -1.f : 0.f);
                 lin = (int64_t)((((size_t)b * C + c0) * H + (size_t)yi) * W + (size_t)xi);
-                atomicAdd(&out[lin], p * (1.f - f));
-                if (c0 + 1 < C) atomicAdd(&out[lin + plane], p * f);
+                if (pv != 0) {
+                    atomicAdd(&out[lin], p * (1.f - f));
+                    if (c0 + 1 < C) atomicAdd(&out[lin + plane], p * f);
+                }
             }
         }
         if (bin0) bin0[i] = c0;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
         tile[k] = -1;
         if (i < P.n) {
             int64_t b, xi, yi;
-            bool neg;
+            bool neg, zero = false;     // polarity is a sign; 0 contributes nothing
             if (P.enc) {
                 xi = P.x16[i];
                 yi = P.y16[i];
@@ -171,7 +175,9 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
                 b = P.sample[i];
                 xi = P.x[i];
                 yi = P.y[i];
-                neg = P.pol[i] < 0;
+                const int64_t pv = P.pol[i];
+                neg = pv < 0;
+                zero = pv == 0;
             }
             int c0 = -1;
             int64_t l = -1;
@@ -184,10 +190,10 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
                     frac[k] = tn - (float)c0;
                     l = (int64_t)((((size_t)b * P.C + c0) * P.H + (size_t)yi) * P.W + (size_t)xi);
                     const int ty = (int)yi / VT, tx = (int)xi / VT;
-                    tile[k] = ((int)b * P.TY + ty) * P.TX + tx;
+                    if (!zero) tile[k] = ((int)b * P.TY + ty) * P.TX + tx;
                     key[k] = (unsigned)(((int)yi - ty * VT) * VT + ((int)xi - tx * VT)) |
                              ((unsigned)c0 << 10) | (neg ? 0x80000000u : 0u);
-                    rank[k] = atomicAdd(&hist[tile[k]], 1);
+                    if (!zero) rank[k] = atomicAdd(&hist[tile[k]], 1);
                 }
             }
             lin[k] = l;

@@ -5,16 +5,15 @@ reference's ``utils/dataset.py`` (select_*_ranges :28-156, join_batches
 :159-198, encode/decode_batch(_info) :201-373, encode/decode_quantized_batch
 :429-502); pinned bit-exact by the literal goldens of
 ``tests/dataset/test_encoding.py`` and ``tests/dataset/test_quantization.py``
-(extracted as data into tests/golden/encoding.pt).  HDF5 read/write is the
-reference's (h5py) and not rebuilt here.
+(extracted as data into tests/golden/encoding.pt).  The HDF5 container of
+these dictionaries is ``hdf5io`` (libhdf5 through ctypes; h5py is absent),
+the loader over it ``preprocessed.PreprocessedDataloader``.
 
 The encoded event columns (int16 x, int16 y, float32 timestamp, bool
 polarity = 9 bytes/event) can be voxelised on the GPU without expanding them
 to the 44-byte int64 wire format: ``voxelize_encoded``.
 """
 import torch
-
-from . import _lib
 
 
 def cumsum_with_prefix(tensor, dtype=None):
@@ -201,32 +200,21 @@ def sample_event_offsets(encoded):
     return ev_shift[el_shift]
 
 
+def compact_events(encoded):
+    """Encoded batch -> the compact event dict ``Model.forward`` accepts in
+    place of the int64 wire columns (voxel.is_compact): the four encoded
+    columns as stored plus ``sample_event_offsets``."""
+    ev = encoded['events']
+    return {'x': ev['x'], 'y': ev['y'], 'timestamp': ev['timestamp'],
+            'polarity': ev['polarity'],
+            'sample_event_offsets': sample_event_offsets(encoded)}
+
+
 def voxelize_encoded(encoded, t0, t1, C, H, W, device='cuda', debug=False):
     """Encoded batch (host or device tensors) -> float32 grid [B,C,H,W] with
     the arithmetic of docs/VOXEL_SPEC.md, reading the 9 B/event columns."""
-    ev = encoded['events']
+    from .voxel import voxelize_compact
     dev = torch.device(device)
-    x = ev['x'].to(dev, torch.short).contiguous()
-    y = ev['y'].to(dev, torch.short).contiguous()
-    t = ev['timestamp'].to(dev, torch.float32).contiguous()
-    p = ev['polarity'].to(dev, torch.uint8).contiguous()
-    off = sample_event_offsets(encoded).to(dev).contiguous()
-    B, n = off.numel() - 1, x.numel()
-    _lib.require_cuda(x, t0.to(dev))
-    t0, t1 = t0.to(dev).contiguous(), t1.to(dev).contiguous()
-    out = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
-    bin0 = lin0 = None
-    if debug:
-        bin0 = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-    lib = _lib.lib()
-    nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
-    _lib.check(lib.dvsof_voxelize_encoded(
-        x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(),
-        off.data_ptr(), n, t0.data_ptr(), t1.data_ptr(), B, C, H, W,
-        out.data_ptr(), _lib.ptr(bin0), _lib.ptr(lin0), _lib.ptr(ws), nbytes,
-        _lib.stream()), 'dvsof_voxelize_encoded')
-    if debug:
-        return out, bin0[:n], lin0[:n]
-    return out
+    ev = compact_events(encoded)
+    B = ev['sample_event_offsets'].numel() - 1
+    return voxelize_compact(ev, t0.to(dev), t1.to(dev), B, C, H, W, debug)

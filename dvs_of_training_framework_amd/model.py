@@ -1,54 +1,62 @@
-"""Plugin loader with the reference's behaviour (utils/model.py:10-47):
-``<flownet_path.name>.net`` is imported BY NAME from sys.path, the kwargs of
-``options2model_kwargs`` are filtered by ``Model.__init__``'s signature, an
-optional ``--sp`` state dict is loaded, the model is moved to the device.
-``--flownet_path dvs_of_training_framework_amd`` selects the HIP build;
-any other package that honours the contract (e.g. DummyNet) still loads."""
+"""Plugin loader: the surface of the reference's ``utils/model.py``.
+
+Contract kept (reference utils/model.py:10-47): the backend is the package
+whose NAME is the last component of ``--flownet_path`` and it is looked up on
+``sys.path`` (not by file path); its ``net.Model`` is constructed as
+``Model(device, **kw)`` where ``kw`` are those of ``options2model_kwargs`` that
+the constructor can take; ``--sp`` optionally names a state dict (bare, or a
+checkpoint with a ``'model'`` entry, utils/serializer.py:99); the model ends up
+on ``device``.  ``--flownet_path dvs_of_training_framework_amd`` selects the
+HIP build; any other package that honours the contract (DummyNet) loads too.
+"""
 import importlib
 import importlib.util
 import inspect
 import logging
-from pathlib import Path
+from pathlib import PurePath
 
 import torch
 
 from .options import options2model_kwargs
 
+log = logging.getLogger(__name__)
+
 
 def filter_kwargs(func, kwargs):
-    signature = inspect.signature(func)
-    keys2use = []
-    for key in signature.parameters:
-        # a **kwargs parameter accepts everything
-        if signature.parameters[key].kind == inspect.Parameter.VAR_KEYWORD:
-            return kwargs
-        if key in kwargs:
-            keys2use.append(key)
-    keys_not2use = [k for k in kwargs if k not in signature.parameters]
-    if len(keys_not2use):
-        logging.warning(f'{keys_not2use} are filtered out from '
-                        'OpticalFlow parameters!')
-    return {key: kwargs[key] for key in keys2use}
+    """The subset of ``kwargs`` that ``func`` accepts by name; everything if
+    it has a ``**`` catch-all.  Dropped names are reported once."""
+    params = inspect.signature(func).parameters
+    if any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values()):
+        return kwargs
+    taken = {name: value for name, value in kwargs.items() if name in params}
+    dropped = sorted(set(kwargs) - set(taken))
+    if dropped:
+        log.warning('model constructor does not take %s: not passed', dropped)
+    return taken
 
 
-def import_module(module_name, module_path):
-    module_spec = importlib.util.find_spec(module_name)
-    assert module_spec is not None, f'Module: {module_name} at ' \
-        f'{Path(module_path).resolve()} not found'
-    return importlib.import_module(module_name)
+def load_backend(flownet_path):
+    """``<flownet_path.name>.net`` as a module.  A missing package raises
+    ModuleNotFoundError (from find_spec), a package without ``net`` fails the
+    assertion -- the two failure modes of the reference's loader."""
+    package = PurePath(flownet_path).name
+    name = f'{package}.net'
+    spec = importlib.util.find_spec(name)
+    assert spec is not None, \
+        f'backend module {name} (from --flownet_path {flownet_path}) not found'
+    return importlib.import_module(name)
+
+
+def _weights_from(path, device):
+    blob = torch.load(path, map_location=device, weights_only=True)
+    return blob.get('model', blob) if isinstance(blob, dict) else blob
 
 
 def init_model(args, device):
-    module = import_module(f'{Path(args.flownet_path).name}.net',
-                           Path(args.flownet_path) / 'net.py')
-    model_kwargs = options2model_kwargs(args)
-    model_kwargs = filter_kwargs(module.Model, model_kwargs)
-    model = module.Model(device, **model_kwargs)
-    if getattr(args, 'sp', None) is not None:
-        state_dict = torch.load(args.sp, map_location=device,
-                                weights_only=True)
-        if 'model' in state_dict:
-            state_dict = state_dict['model']
-        model.load_state_dict(state_dict)
-    model.to(device)
-    return model
+    backend = load_backend(args.flownet_path)
+    kwargs = filter_kwargs(backend.Model, options2model_kwargs(args))
+    model = backend.Model(device, **kwargs)
+    start_point = getattr(args, 'sp', None)
+    if start_point is not None:
+        model.load_state_dict(_weights_from(start_point, device))
+    return model.to(device)

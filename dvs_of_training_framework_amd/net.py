@@ -44,6 +44,11 @@ class VoxelGrid(nn.Module):
         self.depth = depth
 
     def forward(self, events, t0, t1, batch, height, width):
+        """events: the int64 wire columns (utils/dataset.py:961-1020) or the
+        compact 9 B/event columns (voxel.is_compact)."""
+        if voxel.is_compact(events):
+            return voxel.voxelize_compact(events, t0, t1, batch, self.depth,
+                                          height, width)
         return voxel.voxelize(events, t0, t1, batch, self.depth, height, width)
 
 

@@ -41,6 +41,34 @@ class _FusedBase(torch.optim.Optimizer):
             self._init_state(p, st)
         return st
 
+    def load_state_dict(self, state_dict):
+        """torch's loader keeps the SAVED strides of state tensors; a state
+        dict written by ``torch.optim.AdamW`` (the reference's optimizer, or a
+        CPU run) holds contiguous moments while the conv weights here are
+        channels_last.  The kernels index parameter, gradient and state with
+        one offset, so state is re-laid to its parameter's strides."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for p in group['params']:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                shared = {}     # RAdam aliases slow_buffer to exp_avg
+                for name in self.STATE:
+                    v = st.get(name)
+                    if not torch.is_tensor(v):
+                        continue
+                    if id(v) in shared:
+                        st[name] = shared[id(v)]
+                        continue
+                    if v.stride() != p.stride() or v.dtype != p.dtype or \
+                            v.device != p.device:
+                        st[name] = torch.empty_like(p).copy_(v)
+                    shared[id(v)] = st[name]
+                if torch.is_tensor(st.get('step')):
+                    st['step'] = int(st['step'])
+        self._tables = {}
+
     def _table(self, gi, plist):
         """Device tables for group gi; rebuilt only when a pointer moved."""
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)

@@ -421,6 +421,12 @@ class Predictor(nn.Module):
         unit_bucket = {u: b for b, units in enumerate(self.BUCKETS)
                        for u in units}
         reducer = self.reducer
+        dev, on_gpu = params[0].device, params[0].is_cuda
+        # The units of one bucket may be enqueued on different streams (the
+        # backward splits weight gradients between its two streams).  Whoever
+        # closes the bucket hands it to the reducer / the fused optimizer on
+        # ITS stream, so that stream first waits for the other units' writes.
+        marks = [[] for _ in self.BUCKETS]
 
         def finish(unit):
             for i in self.UNIT_PARAMS[unit]:
@@ -431,6 +437,16 @@ class Predictor(nn.Module):
                     p.grad = views[i]
             b = unit_bucket[unit]
             remaining[b] -= 1
+            if on_gpu and len(self.BUCKETS[b]) > 1:
+                cur = torch.cuda.current_stream(dev)
+                if remaining[b] != 0:
+                    done = torch.cuda.Event()
+                    done.record(cur)
+                    marks[b].append((cur, done))
+                else:
+                    for stream, done in marks[b]:
+                        if stream != cur:
+                            cur.wait_event(done)
             if remaining[b] != 0:
                 return
             hook = getattr(self, 'bucket_hook', None)    # optim.fuse_into_backward

@@ -58,3 +58,46 @@ def voxelize(events, t0, t1, B, C, H, W, debug=False):
     if debug:
         return out, bin0[:n], lin0[:n]
     return out
+
+
+COMPACT_KEYS = ('x', 'y', 'timestamp', 'polarity', 'sample_event_offsets')
+
+
+def is_compact(events):
+    """Compact event columns = the reference's ENCODED columns
+    (utils/dataset.py:286-289: int16 x, int16 y, float32 timestamp, bool
+    polarity; 9 bytes/event) plus ``sample_event_offsets`` int64[B+1], the
+    first event of every sample (what ``events_per_element`` /
+    ``elements_per_sample`` add up to, encoding.sample_event_offsets)."""
+    return isinstance(events, dict) and 'sample_event_offsets' in events
+
+
+def voxelize_compact(events, t0, t1, B, C, H, W, debug=False):
+    """Voxel grid [B,C,H,W] straight from the 9 B/event compact columns
+    (dvsof_voxelize_encoded): no expansion to the 44 B/event wire format."""
+    dev = t0.device
+    x = events['x'].to(dev, torch.short).contiguous()
+    y = events['y'].to(dev, torch.short).contiguous()
+    t = events['timestamp'].to(dev, torch.float32).contiguous()
+    p = events['polarity'].to(dev, torch.uint8).contiguous()
+    off = events['sample_event_offsets'].to(dev, torch.long).contiguous()
+    _lib.require_cuda(x, t0, t1)
+    assert off.numel() == B + 1, 'one offset per sample plus the end'
+    n = x.numel()
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+    bin0 = lin0 = None
+    if debug:
+        bin0 = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    lib = _lib.lib()
+    nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    _lib.check(lib.dvsof_voxelize_encoded(
+        x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(),
+        off.data_ptr(), n, t0.contiguous().data_ptr(),
+        t1.contiguous().data_ptr(), B, C, H, W, out.data_ptr(),
+        _lib.ptr(bin0), _lib.ptr(lin0), ws.data_ptr(), nbytes, _lib.stream()),
+        'dvsof_voxelize_encoded')
+    if debug:
+        return out, bin0[:n], lin0[:n]
+    return out

@@ -242,7 +242,7 @@ void orc_count_image(const int64_t *x, const int64_t *y, int64_t n, int H, int W
  *   dt = t1-t0;  tn = dt > 0 ? ((t - t0) / dt) * (C-1) : 0          (all fp32)
  *   dropped if t < t0, t > t1, or x,y outside the frame
  *   c0 = (int)floorf(tn), f = tn - c0
- *   V[b,c0,y,x] += p*(1-f);   if (c0+1 < C) V[b,c0+1,y,x] += p*f
+ *   V[b,c0,y,x] += s*(1-f);   if (c0+1 < C) V[b,c0+1,y,x] += s*f,  s = sign(p)
  * bin0[i] receives c0 (or -1 when dropped) and lin0[i] the linear index of
  * (b,c0,y,x) -- the integer part that must be bit-exact on the GPU.
  * Callers: utils/training.py:59-64, scripts/quantize_preprocessed.py:87-91;
@@ -268,7 +268,7 @@ void orc_voxelize(const int64_t *x, const int64_t *y, const float *t,
         if (c0 > C - 1) c0 = C - 1;
         const float f = tn - (float)c0;
         const size_t base = (((size_t)b * C + c0) * H + (size_t)y[i]) * W + (size_t)x[i];
-        const float pol = (float)p[i];
+        const float pol = p[i] > 0 ? 1.f : (p[i] < 0 ? -1.f : 0.f); /* a sign */
         acc[base] += (double)(pol * (1.f - f));
         if (c0 + 1 < C) acc[base + (size_t)H * W] += (double)(pol * f);
         if (bin0) bin0[i] = c0;

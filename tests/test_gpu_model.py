@@ -161,6 +161,49 @@ def test_fused_adamw_matches_torch():
     assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'}
 
 
+def test_fused_adamw_resumes_from_a_torch_adamw_state_dict():
+    """Checkpoint interchange (utils/serializer.py:60-110 stores
+    optimizer.state_dict()): state written by torch.optim.AdamW(amsgrad=True)
+    holds CONTIGUOUS moments; the conv weights here are channels_last.
+    Loading re-lays the state to the parameter's strides and the next steps
+    match torch's."""
+    from dvs_of_training_framework_amd.optim import FusedAdamW
+    torch.manual_seed(8)
+    shapes = [(64, 5, 3, 3), (64,), (2, 32, 1, 1)]
+    ps = [torch.randn(s) for s in shapes]
+    b = [p.clone().requires_grad_(True) for p in ps]
+    to = torch.optim.AdamW(b, lr=1e-3, weight_decay=1e-2, amsgrad=True)
+    gs = [[torch.randn(s) for s in shapes] for _ in range(4)]
+    for step in range(2):
+        for y, g in zip(b, gs[step]):
+            y.grad = g.clone()
+        to.step()
+    sd = to.state_dict()
+    a = []
+    for y in b:
+        q = y.detach().clone().cuda()
+        if q.dim() == 4:
+            q = q.contiguous(memory_format=torch.channels_last)
+        a.append(q.requires_grad_(True))
+    fo = FusedAdamW(a, lr=1e-3, weight_decay=1e-2, amsgrad=True)
+    fo.load_state_dict(sd)
+    st = fo.state[a[0]]
+    assert st['exp_avg'].stride() == a[0].stride() and st['step'] == 2
+    for step in range(2, 4):
+        for x, y, g in zip(a, b, gs[step]):
+            y.grad = g.clone()
+            gx = g.cuda()
+            x.grad = gx.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else gx
+        fo.step()
+        to.step()
+        for x, y in zip(a, b):
+            assert (x.detach().cpu() - y.detach()).abs().max() <= 2e-6 * y.abs().max()
+    # and back: torch loads what the fused optimizer saved
+    to2 = torch.optim.AdamW([y.detach().clone().requires_grad_(True) for y in b], lr=1e-3,
+                            weight_decay=1e-2, amsgrad=True)
+    to2.load_state_dict(fo.state_dict())
+
+
 def test_train_loop_reduces_loss_and_accumulates():
     import train_flownet as tf
     from dvs_of_training_framework_amd.loss import init_losses

@@ -166,6 +166,10 @@ def test_combined_loss_and_lazy_terms():
     assert float(loss) == pytest.approx(0.5 * 2 + 1 * 4)         # utils/training.py:23
     vals = [list(t) for t in training._lazy_items(terms)]
     assert vals == [[2.0] * 4, [4.0] * 4, [0.0] * 4]
+    # the way train()/validate() consume them (utils/training.py:154,170-173):
+    # all three rows are unpacked FIRST and read afterwards
+    smooth, photo, border = training.TermReadback(terms)
+    assert (list(border), list(smooth), list(photo)) == ([0.0] * 4, [2.0] * 4, [4.0] * 4)
 
 
 def test_train_loop_protocol():
@@ -189,6 +193,14 @@ def test_train_loop_protocol():
     assert 'General/learning rate/0' in tags and 'Train/out regularization/2x2' in tags
     first = [r for r in log.rows if r[0] == 'General/Train loss'][0]
     assert first[2] == 4 and first[1] == pytest.approx(2.5)   # x axis = samples_passed
+    # every family logs ITS term (the fake's flows are `scale`, so at step one
+    # smoothness = 1, photometric = 2, out-of-border = 0 on every scale),
+    # averaged over the two micro-batches
+    at4 = {t: v for t, v, x in log.rows if x == 4}
+    assert at4['Train/smoothness loss/16x16'] == pytest.approx(1.0)
+    assert at4['Train/photometric loss/16x16'] == pytest.approx(2.0)
+    assert at4['Train/out regularization/16x16'] == pytest.approx(0.0)
+    assert at4['General/learning rate/0'] == pytest.approx(0.1)
     # oversize batches are skipped, not counted (utils/training.py:141-150)
     calls.clear()
     training.train(model, 'cpu', _loader(4, events=50), opt, num_steps=2, scheduler=sch,
@@ -206,4 +218,14 @@ def test_validate_loop_tags():
     training.validate(Fake('cpu'), 'cpu', list(_loader(2)), 7, log, _Evaluator())
     assert ('General/Validation loss', pytest.approx(2.5), 7) in \
         [(t, v, x) for t, v, x in log.rows]
-    assert any(t == 'Validation/smoothness loss/16x16' for t, _, _ in log.rows)
+    vals = {t: v for t, v, _ in log.rows}
+    assert vals['Validation/smoothness loss/16x16'] == pytest.approx(1.0)
+    assert vals['Validation/photometric loss/2x2'] == pytest.approx(2.0)
+    assert vals['Validation/out regularization loss/4x4'] == pytest.approx(0.0)
+
+
+def test_make_hook_periodic():
+    seen = []
+    h = training.make_hook_periodic(lambda step, sp: seen.append((step, sp)) or 'ran', 3)
+    assert [h(s, 10 * s) for s in range(1, 7)] == [None, None, 'ran', None, None, 'ran']
+    assert seen == [(3, 30), (6, 60)]
