@@ -13,9 +13,11 @@ HBM before the timed region starts.
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
-`roofline` (dominant kernel: algorithmic FLOPs / HIP-event time, measured on
-the launch stream) and, at N=1, `cpu_baseline` (the CPU port of the same step
-timed on the host cores over a bounded sample).
+`roofline` (dominant conv kernel: FLOPs the matrix cores execute / HIP-event
+time on the launch stream / dense peak, so `frac` <= 1; the algorithmic
+SURVEY-8d figure beside it; `roofline.hbm`: voxelise and pyramid+warp/loss
+call paths against 8 TB/s) and, at N=1, `cpu_baseline` (the CPU port of the
+same step timed on the host cores over a bounded sample).
 """
 import argparse
 import json
@@ -151,16 +153,19 @@ def executed_flops(desc, kind):
     return f
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC
-    passes (profiles/round1/j_traffic_pmc.csv, made by tools/pmc_traffic.py: FETCH_SIZE x2 for the gfx950
-    under-count + WRITE_SIZE, separate --pmc runs of tools/conv_bench.py on the
-    same workload).  PMC cannot be collected from inside this process, so this
-    is a recorded measurement, not a live one; None if the file is absent."""
+def recorded_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed
+    rocprofv3 PMC passes (profiles/round*/..._traffic_pmc.csv, made by
+    tools/pmc_traffic.py: FETCH_SIZE x2 for the gfx950 under-count +
+    WRITE_SIZE, separate --pmc runs of tools/conv_bench.py on this workload).
+    Hardware counters cannot be read from inside this process, so the bench
+    line's `traffic` is null and this RECORDED figure sits beside it with its
+    source; it goes stale when a kernel changes."""
     import csv
-    path = ROOT / 'profiles' / 'round1' / 'j_traffic_pmc.csv'
-    if not path.exists():
+    files = sorted((ROOT / 'profiles').glob('round*/*traffic_pmc.csv'))
+    if not files:
         return None
+    path = files[-1]
     prefix = kernel.split('>')[0]          # e.g. gconv2_kernel<2,2,1,1
     num = den = 0.0
     with open(path) as f:
@@ -171,16 +176,39 @@ def pmc_traffic(kernel):
                 n = float(row['n'])
                 num += n * (float(row['fetch_MB']) + float(row['write_MB'])) * 1e6
                 den += n
-    return round(num / den) if den else None
+    if not den:
+        return None
+    return {'bytes_per_launch': round(num / den),
+            'source': str(path.relative_to(ROOT)) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                      'passes, FETCH x2 on gfx950)'}
+
+
+PEAK_HBM_TBS = 8.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def hbm_bytes(a):
+    """Algorithmic bytes per step of the two HBM-bound call paths."""
+    n_ev = a.batch * (a.events or a.height * a.width)
+    vox = n_ev * 44 + a.batch * a.bins * a.height * a.width * 4
+    px = sum((a.height >> k) * (a.width >> k) for k in range(4))
+    frames = 2 * a.batch
+    pyramid = 4 * frames * (a.height * a.width + px)
+    loss = 40 * a.batch * px
+    return vox, pyramid + loss
 
 
 def measure_roofline(h, step_ms, steps=3):
-    """Per-launch HIP-event timing of every conv-stack launch on torch's
-    current stream (= the launch stream); groups by kernel template."""
-    from dvs_of_training_framework_amd import conv as C
+    """HIP-event timing, on torch's current stream (= the launch stream), of
+    every conv-stack launch (grouped by kernel template) and of the two
+    HBM-bound call paths (voxelise; pyramid + warp/loss forward+backward)."""
+    from dvs_of_training_framework_amd import conv as C, loss as L, voxel as V
     lib = C._lib.lib()
-    records = []
+    records, hbm_rec = [], {'voxelise': [], 'warp+loss': []}
     orig = (C.conv_fwd, C.conv_dgrad, C.conv_wgrad)
+    orig_vox, orig_fused = V.voxelize, L.Losses.fused
+
+    def pair():
+        return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def wrap(fn, kind, family):
         def inner(desc, *args, **kw):
@@ -188,8 +216,7 @@ def measure_roofline(h, step_ms, steps=3):
             tile = lib.dvsof_conv2d_tile_id(ctypes.byref(desc), kind)
             gen = lib.dvsof_conv2d_kernel_generation(ctypes.byref(desc), kind)
             wino = lib.dvsof_conv2d_winograd_tile(ctypes.byref(desc), kind)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
+            e0, e1 = pair()
             e0.record()
             out = fn(desc, *args, **kw)
             e1.record()
@@ -197,17 +224,33 @@ def measure_roofline(h, step_ms, steps=3):
                             e0, e1, executed_flops(desc, kind)))
             return out
         return inner
+
+    def timed(fn, key):
+        def inner(*args, **kw):
+            e0, e1 = pair()
+            e0.record()
+            out = fn(*args, **kw)
+            e1.record()
+            hbm_rec[key].append((e0, e1))
+            return out
+        return inner
+
     def collect():
         del records[:]
+        for v in hbm_rec.values():
+            del v[:]
         C.conv_fwd = wrap(orig[0], 0, 'gconv')
         C.conv_dgrad = wrap(orig[1], 1, 'gconv')
         C.conv_wgrad = wrap(orig[2], 2, 'wgrad')
+        V.voxelize = timed(orig_vox, 'voxelise')
+        L.Losses.fused = timed(orig_fused, 'warp+loss')
         try:
             for _ in range(steps):
                 h.step()
             torch.cuda.synchronize()
         finally:
             C.conv_fwd, C.conv_dgrad, C.conv_wgrad = orig
+            V.voxelize, L.Losses.fused = orig_vox, orig_fused
         out = {}
         for name, fl, e0, e1, xfl in records:
             d = out.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -215,66 +258,71 @@ def measure_roofline(h, step_ms, steps=3):
             d[1] += fl
             d[2] += e0.elapsed_time(e1) * 1e-3
             d[3] += xfl
-        return out
-    agg = collect()             # as timed: two backward streams, launches overlap
+        hbm = {k: sum(e0.elapsed_time(e1) for e0, e1 in v) * 1e-3 / max(len(v), 1)
+               for k, v in hbm_rec.items()}
+        return out, hbm
+    agg, hbm_t = collect()      # as timed: two backward streams, launches overlap
     # the same launches one at a time (second backward stream off): what a kernel
     # does when it has the GPU to itself
     prev = os.environ.get('DVSOF_WGRAD_STREAM')
     os.environ['DVSOF_WGRAD_STREAM'] = '0'
     try:
-        alone = collect()
+        alone, _ = collect()
     finally:
         if prev is None:
             del os.environ['DVSOF_WGRAD_STREAM']
         else:
             os.environ['DVSOF_WGRAD_STREAM'] = prev
-    table = {k: dict(launches=v[0] // steps, gflop_per_step=v[1] / steps / 1e9,
-                     ms_per_step=v[2] / steps * 1e3,
-                     tflops=v[1] / v[2] / 1e12,
-                     executed_tflops=v[3] / v[2] / 1e12) for k, v in agg.items()}
-    dom = max(agg, key=lambda k: agg[k][2])
-    n, fl, sec, xfl = agg[dom]
-    total_fl = sum(v[1] for v in agg.values())
-    total_s = sum(v[2] for v in agg.values())
-    total_x = sum(v[3] for v in agg.values())
     peak = PEAK_BF16_MATRIX_TFLOPS if getattr(h.a, 'dtype', 'f32') != 'f32' \
         else PEAK_F32_MATRIX_TFLOPS
-    roof = {'bound': 'mfma', 'kernel': dom,
-            'achieved': round(fl / sec / 1e12, 2),
-            'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(fl / sec / 1e12 / peak, 4),
-            'traffic': pmc_traffic(dom),
-            'traffic_source': 'profiles/round1/j_traffic_pmc.csv (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950; bytes/launch)',
-            'avg_launch_us': round(sec / n * 1e6, 2),
-            # the dominant kernel with the second backward stream switched off
-            # (no other kernel on the GPU): same launches, same inputs
-            'single_stream': {
-                'achieved': round(alone[dom][1] / alone[dom][2] / 1e12, 2),
-                'frac': round(alone[dom][1] / alone[dom][2] / 1e12 / peak, 4),
-                'avg_launch_us': round(alone[dom][2] / alone[dom][0] * 1e6, 2),
-                'conv_stack_tflops': round(sum(v[1] for v in alone.values()) /
-                                           sum(v[2] for v in alone.values()) / 1e12, 2)},
-            'gflop_per_launch': round(fl / n / 1e9, 3),
-            # FLOPs actually issued to the matrix cores (sub-pixel / phased
-            # decompositions change the count): the hardware-utilisation view
-            'executed_tflops': round(xfl / sec / 1e12, 2),
-            'executed_frac': round(xfl / sec / 1e12 / peak, 4),
-            # whole step: conv FLOPs of one step / measured step time (a lower
-            # bound of the stack's rate: the step also voxelises, evaluates the
-            # loss and runs the optimizer)
-            'step_conv_tflops': round(total_fl / steps / step_ms / 1e9, 2),
-            'step_conv_frac': round(total_fl / steps / step_ms / 1e9 /
-                                    peak, 4),
-            'step_conv_executed_tflops': round(total_x / steps / step_ms / 1e9, 2),
-            # sums of per-launch durations: the backward runs weight gradients
-            # on a second stream beside the data gradients, so launches overlap
-            # and these sums exceed the wall time they cover
-            'conv_stack_executed_tflops': round(total_x / total_s / 1e12, 2),
-            'conv_stack_tflops': round(total_fl / total_s / 1e12, 2),
-            'conv_stack_frac': round(total_fl / total_s / 1e12 /
-                                     peak, 4),
-            'per_kernel': {k: {kk: round(vv, 3) for kk, vv in v.items()}
-                           for k, v in table.items()}}
+    T = 1e12
+
+    def rates(v):       # (launches, algorithmic flops, seconds, executed flops)
+        return {'launches': v[0] // steps, 'avg_launch_us': round(v[2] / v[0] * 1e6, 2),
+                'ms_per_step': round(v[2] / steps * 1e3, 3),
+                'executed_tflops': round(v[3] / v[2] / T, 2),
+                'frac': round(v[3] / v[2] / T / peak, 4),
+                'algorithmic_tflops': round(v[1] / v[2] / T, 2)}
+    dom = max(agg, key=lambda k: agg[k][2])
+    n, fl, sec, xfl = agg[dom]
+    tot = [sum(v[i] for v in agg.values()) for i in range(4)]
+    tot_alone = [sum(v[i] for v in alone.values()) for i in range(4)]
+    vox_b, loss_b = hbm_bytes(h.a)
+    hbm = {}
+    for key, nbytes in (('voxelise', vox_b), ('warp+loss', loss_b)):
+        t = hbm_t[key]
+        if t > 0:
+            hbm[key] = {'bound': 'hbm', 'algorithmic_bytes': nbytes,
+                        'call_path_us': round(t * 1e6, 2),
+                        'achieved': round(nbytes / t / 1e9, 1), 'peak': PEAK_HBM_TBS * 1e3,
+                        'unit': 'GB/s', 'frac': round(nbytes / t / 1e12 / PEAK_HBM_TBS, 4)}
+    roof = {
+        # dominant kernel group: FLOPs the matrix cores EXECUTE per launch (the
+        # sub-pixel / phase / Winograd forms issue fewer than the layer's
+        # algorithmic 2*Ho*Wo*Cout*Cin*k^2) / HIP-event duration / dense peak
+        'bound': 'mfma', 'kernel': dom,
+        'achieved': round(xfl / sec / T, 2), 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': round(xfl / sec / T / peak, 4),
+        'traffic': None,        # PMC counters are not readable in-process
+        'traffic_recorded': recorded_traffic(dom),
+        'avg_launch_us': round(sec / n * 1e6, 2),
+        'gflop_per_launch_executed': round(xfl / n / 1e9, 3),
+        'gflop_per_launch_algorithmic': round(fl / n / 1e9, 3),
+        # SURVEY 8d figure for the same launches (what the layer computes as
+        # specified; may exceed the peak because fewer FLOPs are issued)
+        'algorithmic_tflops': round(fl / sec / T, 2),
+        # the same launches with the second backward stream off (GPU to itself)
+        'single_stream': rates(alone[dom]),
+        # every conv launch of a step: sum of per-launch durations (launches of
+        # the two backward streams overlap, so these sums exceed wall time)
+        'conv_stack': rates(tot), 'conv_stack_single_stream': rates(tot_alone),
+        # whole step: executed conv FLOPs of a step / measured step time (the step
+        # also voxelises, evaluates the loss and runs the optimizer)
+        'step': {'executed_tflops': round(tot[3] / steps / step_ms / 1e9, 2),
+                 'frac': round(tot[3] / steps / step_ms / 1e9 / peak, 4),
+                 'algorithmic_tflops': round(tot[1] / steps / step_ms / 1e9, 2)},
+        'hbm': hbm,
+        'per_kernel': {k: rates(v) for k, v in agg.items()}}
     return roof
 
 
@@ -313,16 +361,23 @@ def cpu_baseline(a):
         opt.zero_grad(set_to_none=True)
         return loss
     step()                                  # warm-up
-    n, t = 0, time.perf_counter()
-    while n < 2 or (time.perf_counter() - t < 10 and n < 20):
+    per_step, t = [], time.perf_counter()
+    while len(per_step) < 3 or (time.perf_counter() - t < 15 and len(per_step) < 30):
+        t1 = time.perf_counter()
         step()
-        n += 1
-    dt = time.perf_counter() - t
+        per_step.append(time.perf_counter() - t1)
+    dt, n = time.perf_counter() - t, len(per_step)
+    rate = sorted(B / x for x in per_step)
     return {'value': round(B * n / dt, 3), 'unit': 'samples/s', 'cores': cores,
             'kind': 'port',
+            # this figure moves with the host's load and thread placement
+            # (0.8-2.6 samples/s across boxes in round 1): the spread is stated
+            'spread': {'min': round(rate[0], 3), 'median': round(rate[n // 2], 3),
+                       'max': round(rate[-1], 3)},
             'sample': f'{n} steps of batch {B} (of {a.batch}) at '
                       f'{a.height}x{a.width}x{a.bins}, {dt:.1f} s, '
-                      f'torch {cores} threads + scalar C loss/voxel'}
+                      f'torch {cores} threads (ATen predictor + AdamW) + scalar '
+                      'single-thread C voxeliser/loss'}
 
 
 def main():

@@ -35,12 +35,13 @@ _SIGNATURES = {
     'dvsof_voxelize_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                 _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'dvsof_voxelize_workspace_bytes': (_sz, [_i64, _i, _i, _i, _i]),
+    'dvsof_voxelize_control_bytes': (_sz, [_i64, _i, _i, _i, _i]),
     'dvsof_voxelize_tiled': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                   _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
-                                  _vp]),
+                                  _i, _vp]),
     'dvsof_voxelize_encoded': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                     _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
-                                    _vp]),
+                                    _i, _vp]),
     'dvsof_resize_bilinear_ac': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'dvsof_loss_workspace_bytes': (_sz, [ctypes.POINTER(LossScale), _i, _i]),
     'dvsof_loss_fwd': (_i, [ctypes.POINTER(LossScale), _i, _i, _vp, _vp, _vp,

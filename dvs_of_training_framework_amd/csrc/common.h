@@ -26,22 +26,24 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
-// Charbonnier rho(d) = (d^2 + eps^2)^0.45 and rho'(d) from one log2/exp2
-// pair (reference: utils/loss.py:24-35, alpha = 0.45, epsilon = 1e-3).
+// Charbonnier rho(d) = (d^2 + eps^2)^0.45 and rho'(d) from ONE log2 and ONE
+// exp2 (reference: utils/loss.py:24-35, alpha = 0.45, epsilon = 1e-3):
+// e = s^(alpha-1), rho = s * e, rho' = 2 alpha d e.  The transcendental pipe
+// runs at a quarter of the VALU rate and the loss kernel is bound by it.
 struct Charb {
     float val, der;
 };
 __device__ __forceinline__ Charb charbonnier(float d)
 {
     const float s = fmaf(d, d, 1e-6f);
-    const float l = __builtin_amdgcn_logf(s);
+    const float e = __builtin_amdgcn_exp2f(-0.55f * __builtin_amdgcn_logf(s));
     Charb c;
-    c.val = __builtin_amdgcn_exp2f(0.45f * l);
-    // 2*alpha*d*s^(alpha-1): a second v_exp_f32 instead of an IEEE division
-    c.der = 0.9f * d * __builtin_amdgcn_exp2f(-0.55f * l);
+    c.val = s * e;
+    c.der = 0.9f * d * e;
     return c;
 }
 __device__ __forceinline__ float charb_val(float d)
 {
-    return __builtin_amdgcn_exp2f(0.45f * __builtin_amdgcn_logf(fmaf(d, d, 1e-6f)));
+    const float s = fmaf(d, d, 1e-6f);
+    return s * __builtin_amdgcn_exp2f(-0.55f * __builtin_amdgcn_logf(s));
 }

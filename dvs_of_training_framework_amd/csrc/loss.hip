@@ -6,13 +6,28 @@
 // :92-119 (out-of-border), :121-171 (Loss.__call__), and the autograd
 // backward that utils/training.py:158 runs through them.
 //
-// HBM-bound kernels.  Layout: flow [N,2,h,w] and frames [D,h,w] row-major;
-// a 256-thread workgroup owns a 64x16 pixel tile of one sample at one scale,
-// stages the flow tile + 1 px halo in LDS (the 3x3 smoothness stencil reads
-// it 9x), gathers the 4 bilinear taps of the second frame straight from
-// L2/HBM, reduces its sums with wave shuffles and writes ONE partial record;
-// a single-workgroup finalize kernel adds the records in a fixed order
-// (bitwise reproducible, no float atomics).
+// HBM-bound kernels, two launches per evaluation:
+//   A  loss_pyramid_kernel: the cascaded frame pyramid; its tail workgroups
+//      count out-of-border pixels per tile (plain stores, no atomics, nothing
+//      to zero) and workgroup 0 clears the arrival counters of launch B;
+//   B  loss_main_kernel: all scales, forward sums and flow gradients in one
+//      sweep, and the reduction of the sums folded in (below).
+// Layout: flow [N,2,h,w] and frames [D,h,w] row-major.  A 256-thread
+// workgroup owns a 64x16 pixel tile of one sample at one scale: wave v owns
+// rows 4v..4v+3, lane l column l, so a thread holds a 4-pixel column strip.
+// The flow tile + 1 px halo is staged in LDS; the 4 bilinear taps of the
+// second frame are gathered straight from L2/HBM.
+// Smoothness: every neighbour pair is evaluated ONCE, at its anchor pixel
+// (the 4 pairs ->, v, \, / of utils/loss.py:76-90), value and derivative from
+// one log2 + one exp2; the derivative reaches the pair's other pixel through
+// registers (same column), a lane shuffle (column to the left) or a 12-entry
+// LDS row per wave (left tile edge): 19 evaluations per channel and 4-pixel
+// strip instead of 36.
+// Reduction: a workgroup writes ONE partial record; the LAST workgroup of a
+// (scale, sample) group to arrive adds that group's records in a fixed order,
+// the LAST group to finish combines the groups, applies the reference's
+// normalisers and writes the terms -- bitwise reproducible (who is last does
+// not change any order of additions), no float atomics, no finalize launch.
 #include "common.h"
 #include <stdlib.h>
 
@@ -38,12 +53,16 @@ struct Params {
     ScaleDev s[DVSOF_MAX_SCALES];
     int K, N;
     const int32_t *start, *stop;
-    float *partials;
-    int32_t *oob;               // [K*N]
-    double *group;              // [K*N][NGROUP] finalize stage records
-    int *counter;               // finalize arrival counter (zeroed by the main kernel)
+    float *partials;            // [nb][NPART] per-workgroup sums
+    int32_t *oob;               // [K*N] out-of-border pixels per (scale, sample)
+    int32_t *oob_tile;          // [nb] the same per tile (launch A) or null: use oob
+    double *group;              // [K*N][NGROUP] group records
+    int *counter;               // [K*N + 1] arrivals per group, finished groups
     const float *seeds_dev;     // [3*K] or null
     float seeds_host[3];        // used when seeds_dev == null
+    float *terms, *loss_out;    // outputs of the folded reduction
+    float wts[3], loss_scale;
+    int strict_fences;          // agent-scope release/acquire fences around the counters
 };
 
 __device__ __forceinline__ int find_scale(const Params &P, int bid)
@@ -67,15 +86,116 @@ __device__ __forceinline__ bool out_of_border(float gx, float gy)
     return (gx < -1.f) | (gx > 1.f) | (gy < -1.f) | (gy > 1.f);
 }
 
+constexpr int NGROUP = 8;   // doubles per group record: 7 sums + pad
+constexpr int NW = NT / kWave;
+
+// Publish / observe protocol of the folded reduction.  Records are written
+// with agent-scope atomic stores (write-through to the memory side, visible
+// to every XCD once acknowledged: s_waitcnt vmcnt(0)) and read back with
+// agent-scope atomic loads; the arrival counters are agent-scope RMWs.  With
+// strict_fences the RMW is additionally bracketed by the memory model's
+// agent-scope release (before) and acquire (after, in the workgroup that goes
+// on to read) fences -- the textbook fence-reduction pattern.
+__device__ __forceinline__ int arrive(int *counter, int strict)
+{
+    if (strict) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return old;
+}
+__device__ __forceinline__ void publish(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish(float *p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T observe(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Group (k, n): add its tile records in a fixed order (double).  All 256
+// threads; the 7 sums end up in g[0..6] of thread `tid < 7`'s return value.
+__device__ __forceinline__ double group_sum(const Params &P, int k, int n, double (*sh)[7])
+{
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const ScaleDev &S = P.s[k];
+    const float *part = P.partials + ((size_t)S.block_begin + (size_t)n * S.tiles_per_sample) * NPART;
+    double a[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = tid; b < S.tiles_per_sample; b += NT) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) a[i] += (double)observe(part + (size_t)b * NPART + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const double v = wave_sum(a[i]);
+        if (lane == 0) sh[wave][i] = v;
+    }
+    __syncthreads();
+    return tid < 7 ? (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]) : 0.0;
+}
+
+// Last group: items (k, i), i < 5: global sums of photo + the four smoothness
+// directions; i == 5: border term = sum_n bs_n / (2 c_n N) (utils/loss.py:101,113).
+__device__ __forceinline__ void final_terms(const Params &P, double (*s_sum)[6])
+{
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    for (int item = wave; item < P.K * 6; item += NW) {
+        const int kk = item / 6, i = item - 6 * kk;
+        double a = 0;
+        for (int nn = lane; nn < P.N; nn += kWave) {
+            const double *g = P.group + ((size_t)kk * P.N + nn) * NGROUP;
+            if (i < 5) {
+                a += observe(g + i);
+            } else {
+                const double bs = observe(g + 5), c = observe(g + 6);
+                if (c > 0) a += bs / (2.0 * c * (double)P.N);
+            }
+        }
+        a = wave_sum(a);
+        if (lane == 0) s_sum[kk][i] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double total[3] = {0, 0, 0};
+        for (int kk = 0; kk < P.K; ++kk) {
+            const ScaleDev &S = P.s[kk];
+            const double *a = s_sum[kk];
+            // empty crops contribute 0 (utils/loss.py:29-30)
+            const double sm = ((S.c_smooth[0] > 0 ? a[1] / S.c_smooth[0] : 0) +
+                               (S.c_smooth[1] > 0 ? a[2] / S.c_smooth[1] : 0) +
+                               (S.c_smooth[2] > 0 ? (a[3] + a[4]) / S.c_smooth[2] : 0)) / 4.0;
+            const double ph = a[0] / ((double)P.N * S.h * S.w);
+            const double border = a[5];
+            P.terms[0 * P.K + kk] = (float)sm;
+            P.terms[1 * P.K + kk] = (float)ph;
+            P.terms[2 * P.K + kk] = (float)border;
+            total[0] += sm;
+            total[1] += ph;
+            total[2] += border;
+        }
+        if (P.loss_out)  // combined_loss, utils/training.py:23
+            P.loss_out[0] = (float)((P.wts[0] * total[0] + P.wts[1] * total[1] + P.wts[2] * total[2]) /
+                                    (double)P.K * (double)P.loss_scale);
+    }
+}
+
 template <bool FWD, bool BWD>
 __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 {
     __shared__ float sF[2][LH][LW];
-    __shared__ float red[NT / kWave][NPART];
+    __shared__ float sE[NW][2][12];      // left-edge column derivatives, per wave
+    __shared__ float red[NW][NPART];
+    __shared__ int s_flag, s_cnt[NW];
+    __shared__ double s_dbl[NW][7];
+    __shared__ double s_sum[DVSOF_MAX_SCALES][6];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int bid = blockIdx.x;
-    if (FWD && bid == 0 && tid == 0 && P.counter) *P.counter = 0;
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -102,24 +222,35 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             seed[i] = P.seeds_dev ? P.seeds_dev[i * P.K + k] : P.seeds_host[i];
-        const int cnt = P.oob[k * P.N + n];
+        int cnt;
+        if (P.oob_tile) {   // per-tile counts of launch A: integer sum, any order
+            int c = 0;
+            const int32_t *ot = P.oob_tile + S.block_begin + n * S.tiles_per_sample;
+            for (int b = tid; b < S.tiles_per_sample; b += NT) c += ot[b];
+            c = wave_sum(c);
+            if (lane == 0) s_cnt[wave] = c;
+            __syncthreads();
+            cnt = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        } else {
+            cnt = P.oob[k * P.N + n];
+        }
         k_border = cnt > 0 ? seed[2] / (2.f * (float)cnt * (float)P.N) : 0.f;
     }
     __syncthreads();
 
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int tx = tid & (TW - 1), tr = tid >> 6;
-    const int x = tx0 + tx;
-    constexpr int NP = TH / 4;   // pixels per thread (rows tr, tr+4, ...)
+    const int x = tx0 + lane;
+    const int ly0 = wave * 4;            // tile-local row of the strip's first pixel
+    constexpr int NP = 4;                // pixels per thread: rows ly0 .. ly0 + 3
     // phase A: addresses and ALL gathers of the thread's pixels first, so the
     // 5*NP loads are in flight together instead of NP dependent round trips
     bool valid[NP], oobv[NP];
     float uu[NP], vv[NP], axv[NP], ayv[NP], nwv[NP], nev[NP], swv[NP], sev[NP], prv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int ly = tr + 4 * j, y = ty0 + ly;
+        const int ly = ly0 + j, y = ty0 + ly;
         valid[j] = (y < h) & (x < w);
-        const float u = sF[0][ly + 1][tx + 1], v = sF[1][ly + 1][tx + 1];
+        const float u = sF[0][ly + 1][lane + 1], v = sF[1][ly + 1][lane + 1];
         uu[j] = u;
         vv[j] = v;
         float gx, gy;
@@ -141,97 +272,165 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
         sev[j] = (valid[j] & vy1 & vx1) ? r0[w + 1] : 0.f;
         prv[j] = valid[j] ? I0[(size_t)y * w + x] : 0.f;
     }
+
+    // left-edge column (x = tx0 - 1) derivatives the strip's lane 0 needs:
+    // lanes 0..23 of every wave evaluate one each -> sE[wave][channel][kind*4 + r],
+    // kind 0: d0(r, xe), 1: d2(r-1, xe), 2: d3(r, xe)
+    if (BWD) {
+        if (lane < 24) {
+            const int c = lane / 12, q = lane - 12 * c, kind = q >> 2, r = q & 3;
+            const int db = kind == 1 ? -1 : (kind == 2 ? 1 : 0);
+            const int ya = ty0 + ly0 + r, yb = ya + db;
+            const bool ok = (tx0 >= 1) & (ya >= 0) & (ya < h) & (yb >= 0) & (yb < h);
+            const float fa = sF[c][ly0 + r + 1][1], fb = sF[c][ly0 + r + 1 + db][0];
+            sE[wave][c][q] = ok ? charbonnier(fa - fb).der : 0.f;
+        }
+        __syncthreads();
+    }
+
+    float gu[NP], gv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) gu[j] = gv[j] = 0.f;
+    // photometric + out-of-border, utils/loss.py:58-74, 96-119
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int ly = tr + 4 * j, y = ty0 + ly;
         if (!valid[j]) continue;
-        const float u = uu[j], v = vv[j];
-        const bool oob = oobv[j];
         const float ax = axv[j], ay = ayv[j], cx = 1.f - ax, cy = 1.f - ay;
         const float nw = nwv[j], ne = nev[j], sw = swv[j], se = sev[j];
         const float warped = nw * cx * cy + ne * ax * cy + sw * cx * ay + se * ax * ay;
         const Charb ph = charbonnier(warped - prv[j]);
-
-        float gu = 0.f, gv = 0.f;
         if (FWD) acc[0] += ph.val;
         if (BWD) {
             const float gp = seed[1] * S.k_photo * ph.der;
-            gu = gp * ((ne - nw) * cy + (se - sw) * ay);
-            gv = gp * ((sw - nw) * cx + (se - ne) * ax);
+            gu[j] = gp * ((ne - nw) * cy + (se - sw) * ay);
+            gv[j] = gp * ((sw - nw) * cx + (se - ne) * ax);
         }
-        if (oob) {  // utils/loss.py:96-119
-            const Charb bu = charbonnier(u), bv = charbonnier(v);
+        if (oobv[j]) {
+            const Charb bu = charbonnier(uu[j]), bv = charbonnier(vv[j]);
             if (FWD) {
                 acc[5] += bu.val + bv.val;
                 acc[6] += 1.f;
             }
             if (BWD) {
-                gu += k_border * bu.der;
-                gv += k_border * bv.der;
+                gu[j] += k_border * bu.der;
+                gv[j] += k_border * bv.der;
             }
         }
-        // smoothness, utils/loss.py:76-90: pairs (->, v, diag \, diag /)
-        const bool xr = x + 1 < w, xl = x >= 1, yd = y + 1 < h, yu = y >= 1;
+    }
+    // smoothness, utils/loss.py:76-90.  Anchor (r, x), r = -1..3 relative to the
+    // strip: d0 = rho'(F[r][x+1] - F[r][x]), d1 = rho'(F[r+1][x] - F[r][x]),
+    // d2 = rho'(F[r+1][x+1] - F[r][x]), d3 = rho'(F[r][x+1] - F[r+1][x]).
+    // Pixel (r, x) is the SECOND operand of its own d0, d1, d2, the FIRST of
+    // d0(r, x-1), d1(r-1, x), d2(r-1, x-1), d3(r, x-1), the SECOND of d3(r-1, x).
+    {
+        const bool xin = x < w, xr = x + 1 < w;
+        bool rin[6];                       // rows -1..4 of the strip inside the frame
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int y = ty0 + ly0 + r - 1;
+            rin[r] = (y >= 0) & (y < h);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float(*F)[LW] = sF[c];
-            const int a = ly + 1, b = tx + 1;
-            const float ctr = F[a][b];
-            float g = 0.f;
-            if (xr) {
-                const Charb q = charbonnier(F[a][b + 1] - ctr);
-                if (FWD) acc[1] += q.val;
-                if (BWD) g -= S.k_smooth[0] * q.der;
+            float a0[6], a1[6];            // columns x, x+1; rows -1..4
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                a0[r] = sF[c][ly0 + r][lane + 1];
+                a1[r] = sF[c][ly0 + r][lane + 2];
             }
-            if (yd) {
-                const Charb q = charbonnier(F[a + 1][b] - ctr);
-                if (FWD) acc[2] += q.val;
-                if (BWD) g -= S.k_smooth[1] * q.der;
-            }
-            if (xr & yd) {
-                const Charb q = charbonnier(F[a + 1][b + 1] - ctr);
-                if (FWD) acc[3] += q.val;
-                if (BWD) g -= S.k_smooth[2] * q.der;
-                if (FWD) acc[4] += charb_val(F[a][b + 1] - F[a + 1][b]);
+            float d0[5], d1[5], d2[5], d3[5];      // index r + 1
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const bool own = r >= 1;           // anchor row of this strip: sums count
+                const bool p0 = rin[r] & xr, p1 = rin[r] & rin[r + 1] & xin,
+                           p2 = rin[r] & rin[r + 1] & xr;
+                d0[r] = d1[r] = d2[r] = d3[r] = 0.f;
+                if (own && p0) {
+                    const Charb q = charbonnier(a1[r] - a0[r]);
+                    if (FWD) acc[1] += q.val;
+                    d0[r] = q.der;
+                }
+                if (p1) {
+                    const Charb q = charbonnier(a0[r + 1] - a0[r]);
+                    if (FWD && own) acc[2] += q.val;
+                    d1[r] = q.der;
+                }
+                if (p2) {
+                    const Charb q = charbonnier(a1[r + 1] - a0[r]);
+                    if (FWD && own) acc[3] += q.val;
+                    d2[r] = q.der;
+                    const Charb z = charbonnier(a1[r] - a0[r + 1]);
+                    if (FWD && own) acc[4] += z.val;
+                    d3[r] = z.der;
+                }
             }
             if (BWD) {
-                if (xl) g += S.k_smooth[0] * charbonnier(ctr - F[a][b - 1]).der;
-                if (yu) g += S.k_smooth[1] * charbonnier(ctr - F[a - 1][b]).der;
-                if (xl & yu) g += S.k_smooth[2] * charbonnier(ctr - F[a - 1][b - 1]).der;
-                if (xl & yd) g += S.k_smooth[2] * charbonnier(ctr - F[a + 1][b - 1]).der;
-                if (yu & xr) g -= S.k_smooth[2] * charbonnier(F[a - 1][b + 1] - ctr).der;
-                g *= seed[0];
-                if (c == 0) gu += g; else gv += g;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int r = j + 1;
+                    // from the column to the left: lane - 1, or the edge row for lane 0
+                    float in0 = __shfl_up(d0[r], 1, kWave), in2 = __shfl_up(d2[r - 1], 1, kWave),
+                          in3 = __shfl_up(d3[r], 1, kWave);
+                    if (lane == 0) {
+                        in0 = sE[wave][c][j];
+                        in2 = sE[wave][c][4 + j];
+                        in3 = sE[wave][c][8 + j];
+                    }
+                    float g = S.k_smooth[0] * (in0 - d0[r]) + S.k_smooth[1] * (d1[r - 1] - d1[r]) +
+                              S.k_smooth[2] * ((in2 - d2[r]) + (in3 - d3[r - 1]));
+                    g *= seed[0];
+                    if (c == 0) gu[j] += g; else gv[j] += g;
+                }
             }
         }
-        if (BWD) {
-            float *G = S.grad + (size_t)n * 2 * hw + (size_t)y * w + x;
-            G[0] = gu;
-            G[hw] = gv;
+    }
+    if (BWD) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (!valid[j]) continue;
+            float *G = S.grad + (size_t)n * 2 * hw + (size_t)(ty0 + ly0 + j) * w + x;
+            G[0] = gu[j];
+            G[hw] = gv[j];
         }
     }
 
-    if (FWD) {
+    if (!FWD) return;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const float s = wave_sum(acc[i]);
-            if ((tid & (kWave - 1)) == 0) red[tid >> 6][i] = s;
-        }
-        __syncthreads();
-        if (tid < NPART) {
-            float s = 0.f;
-            if (tid < 7)
-                for (int wv = 0; wv < NT / kWave; ++wv) s += red[wv][tid];
-            P.partials[(size_t)bid * NPART + tid] = s;
-        }
+    for (int i = 0; i < 7; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
     }
+    __syncthreads();
+    if (tid < NPART) {
+        float v = 0.f;
+        if (tid < 7) v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        publish(P.partials + (size_t)bid * NPART + tid, v);
+    }
+    // ---- folded reduction: last workgroup of the group, last group overall
+    const int grp = k * P.N + n;
+    if (tid == 0) s_flag = arrive(P.counter + grp, P.strict_fences) == S.tiles_per_sample - 1;
+    __syncthreads();
+    if (!s_flag) return;
+    const double gsum = group_sum(P, k, n, s_dbl);
+    if (tid < 7) {
+        publish(P.group + (size_t)grp * NGROUP + tid, gsum);
+        if (tid == 6) P.oob[grp] = (int)gsum;
+    }
+    __syncthreads();
+    if (tid == 0) s_flag = arrive(P.counter + P.K * P.N, P.strict_fences) == P.K * P.N - 1;
+    __syncthreads();
+    if (!s_flag) return;
+    final_terms(P, s_sum);
 }
 
-// Per-sample out-of-border pixel counts (utils/loss.py:101) ahead of the
-// fused forward+backward sweep.  Integer atomics: order-independent.
+// Per-tile out-of-border pixel counts (utils/loss.py:101) ahead of the fused
+// forward+backward sweep: plain stores, one int per tile.  Workgroup 0 also
+// clears the arrival counters of the main kernel that follows in the stream.
 __device__ __forceinline__ void count_oob_block(const Params &P, int bid, int *red)
 {
     const int tid = threadIdx.x;
+    if (bid == 0 && P.counter)
+        for (int i = tid; i <= P.K * P.N; i += NT) P.counter[i] = 0;
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -256,10 +455,7 @@ __device__ __forceinline__ void count_oob_block(const Params &P, int bid, int *r
     cnt = wave_sum(cnt);
     if ((tid & (kWave - 1)) == 0) red[tid >> 6] = cnt;
     __syncthreads();
-    if (tid == 0) {
-        const int s = red[0] + red[1] + red[2] + red[3];
-        if (s) atomicAdd(&P.oob[k * P.N + n], s);
-    }
+    if (tid == 0) P.oob_tile[bid] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(NT) void loss_count_oob_kernel(const Params P)
@@ -365,103 +561,6 @@ __global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, con
     }
 }
 
-// Finalize: workgroup (k, n) adds the tile records of sample n at scale k in a
-// fixed order (double) into one group record; the LAST workgroup to finish
-// (fence + counter, the standard fence-reduction pattern) adds the group
-// records in a fixed order, applies the reference's normalisers and writes
-// terms[t*K + k], t = smooth/photo/border, and the combined loss.  The result
-// does not depend on which workgroup happens to be last.
-constexpr int NGROUP = 8;   // doubles per group record: 7 sums + pad
-
-__global__ __launch_bounds__(NT) void loss_finalize_kernel(const Params P, double *group,
-                                                           int *counter, float *terms,
-                                                           float *loss_out, float w0, float w1,
-                                                           float w2, float loss_scale,
-                                                           int write_oob)
-{
-    constexpr int NW = NT / kWave;
-    __shared__ double sh[NW][7];
-    __shared__ int s_last;
-    __shared__ double s_sum[DVSOF_MAX_SCALES][6];
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    const int k = blockIdx.x / P.N, n = blockIdx.x - k * P.N;
-    {
-        const ScaleDev &S = P.s[k];
-        const float *part = P.partials + ((size_t)S.block_begin + (size_t)n * S.tiles_per_sample) * NPART;
-        double a[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int b = tid; b < S.tiles_per_sample; b += NT) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) a[i] += (double)part[(size_t)b * NPART + i];
-        }
-        // lanes -> waves -> workgroup: one barrier for all 7 sums
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const double v = wave_sum(a[i]);
-            if (lane == 0) sh[wave][i] = v;
-        }
-        __syncthreads();
-        if (tid < 7) {
-            const double v = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
-            // agent-scope (write-through) store: visible to the last workgroup on
-            // any XCD without a full L2 write-back (__threadfence() costs ~20 us
-            // here: the L2 is full of the step's dirty activations)
-            __hip_atomic_store(&group[(size_t)blockIdx.x * NGROUP + tid], v, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 6 && write_oob) P.oob[k * P.N + n] = (int)v;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged
-        }
-    }
-    __syncthreads();
-    if (tid == 0)
-        s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                 (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    // items (k, i): i < 5 global sums of photo + four smoothness directions,
-    // i == 5: border term = sum_n bs_n / (2 c_n N)  (utils/loss.py:101,113).
-    // Item j belongs to wave j % NW: lane-strided over the samples + shuffle tree.
-    for (int item = wave; item < P.K * 6; item += NW) {
-        const int kk = item / 6, i = item - 6 * kk;
-        double a = 0;
-        for (int nn = lane; nn < P.N; nn += kWave) {
-            const double *g = group + ((size_t)kk * P.N + nn) * NGROUP;
-            if (i < 5) {
-                a += __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                const double bs = __hip_atomic_load(g + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double c = __hip_atomic_load(g + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c > 0) a += bs / (2.0 * c * (double)P.N);
-            }
-        }
-        a = wave_sum(a);
-        if (lane == 0) s_sum[kk][i] = a;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double total[3] = {0, 0, 0};
-        for (int kk = 0; kk < P.K; ++kk) {
-            const ScaleDev &S = P.s[kk];
-            const double *a = s_sum[kk];
-            // empty crops contribute 0 (utils/loss.py:29-30)
-            const double sm = ((S.c_smooth[0] > 0 ? a[1] / S.c_smooth[0] : 0) +
-                               (S.c_smooth[1] > 0 ? a[2] / S.c_smooth[1] : 0) +
-                               (S.c_smooth[2] > 0 ? (a[3] + a[4]) / S.c_smooth[2] : 0)) / 4.0;
-            const double ph = a[0] / ((double)P.N * S.h * S.w);
-            const double border = a[5];
-            terms[0 * P.K + kk] = (float)sm;
-            terms[1 * P.K + kk] = (float)ph;
-            terms[2 * P.K + kk] = (float)border;
-            total[0] += sm;
-            total[1] += ph;
-            total[2] += border;
-        }
-        if (loss_out)  // combined_loss, utils/training.py:23
-            loss_out[0] = (float)((w0 * total[0] + w1 * total[1] + w2 * total[2]) /
-                                  (double)P.K * (double)loss_scale);
-        *counter = 0;   // ready for the next call on this workspace
-    }
-}
-
 // F.interpolate(bilinear, align_corners=True), utils/loss.py:20-21.
 __global__ __launch_bounds__(NT) void resize_bilinear_ac_kernel(const float *__restrict__ src,
                                                                 float *__restrict__ dst,
@@ -514,24 +613,37 @@ int build_params(const dvsof_loss_scale_t *sc, int K, int N, Params &P, int &tot
     return DVSOF_OK;
 }
 
-// workspace: [partials nb*NPART f32][group K*N*NGROUP f64][counter]
+// workspace: [partials nb*NPART f32][group K*N*NGROUP f64][oob_tile nb i32]
+//            [counters (K*N + 1) i32]
 size_t ws_layout(int nb, int K, int N, size_t &group_off, size_t &counter_off)
 {
     size_t o = (size_t)nb * NPART * sizeof(float);
     o = (o + 15) & ~(size_t)15;
     group_off = o;
     o += (size_t)K * N * NGROUP * sizeof(double);
+    o += (size_t)nb * sizeof(int32_t);
+    o = (o + 15) & ~(size_t)15;
     counter_off = o;
-    return o + 16;
+    return o + ((size_t)K * N + 1) * sizeof(int) + 16;
 }
 
-void bind_ws(Params &P, void *ws, int nb)
+void bind_ws(Params &P, void *ws, int nb, float *terms, float *loss_out, const float *w,
+             float loss_scale)
 {
     size_t g, c;
     ws_layout(nb, P.K, P.N, g, c);
     P.partials = (float *)ws;
     P.group = (double *)((char *)ws + g);
+    P.oob_tile = (int32_t *)((char *)ws + g + (size_t)P.K * P.N * NGROUP * sizeof(double));
     P.counter = (int *)((char *)ws + c);
+    P.terms = terms;
+    P.loss_out = loss_out;
+    for (int i = 0; i < 3; ++i) P.wts[i] = w ? w[i] : 0.f;
+    P.loss_scale = loss_scale;
+    // DVSOF_LOSS_RELAXED=1: counters without the agent-scope release/acquire
+    // fences (write-through record stores + s_waitcnt only; see arrive())
+    static const bool relaxed = getenv("DVSOF_LOSS_RELAXED") != nullptr;
+    P.strict_fences = relaxed ? 0 : 1;
 }
 
 // Pyramid plan: fused single launch when the level sizes are non-decreasing
@@ -642,18 +754,6 @@ int dvsof_loss_pyramid(const float *images, int D, int H, int W, float *const *l
     return pyramid_launch(images, D, H, W, levels, hs, ws, K, nullptr, 0, as_stream(stream));
 }
 
-namespace {
-int finalize_launch(const Params &P, float *terms, float *loss_out, const float *w,
-                    float loss_scale, int write_oob, hipStream_t st)
-{
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(P.K * P.N), dim3(NT), 0, st, P, P.group, P.counter,
-                       terms, loss_out, w ? w[0] : 0.f, w ? w[1] : 0.f, w ? w[2] : 0.f, loss_scale,
-                       write_oob);
-    DVSOF_LAUNCH_CHECK();
-    return DVSOF_OK;
-}
-}  // namespace
-
 int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
                    const int32_t *stop, float *terms, int32_t *oob, void *ws, size_t ws_bytes,
                    void *stream)
@@ -667,12 +767,17 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     if (ws_bytes < ws_layout(nb, K, N, g, c)) return DVSOF_ENOSPACE;
     P.start = start;
     P.stop = stop;
-    bind_ws(P, ws, nb);
+    bind_ws(P, ws, nb, terms, nullptr, nullptr, 1.f);
     P.oob = oob;
     P.seeds_dev = nullptr;
+    // launch A (per-tile counts are not needed by a forward-only sweep, but the
+    // same kernel clears the arrival counters), then the sweep with the folded
+    // reduction, which also writes oob[k*N + n] for dvsof_loss_bwd
+    hipLaunchKernelGGL(loss_count_oob_kernel, dim3(nb), dim3(NT), 0, as_stream(stream), P);
+    DVSOF_LAUNCH_CHECK();
     hipLaunchKernelGGL((loss_main_kernel<true, false>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
     DVSOF_LAUNCH_CHECK();
-    return finalize_launch(P, terms, nullptr, nullptr, 1.f, 1, as_stream(stream));
+    return DVSOF_OK;
 }
 
 int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
@@ -690,6 +795,9 @@ int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     P.partials = nullptr;
     P.group = nullptr;
     P.counter = nullptr;
+    P.oob_tile = nullptr;       // totals of the forward call
+    P.terms = P.loss_out = nullptr;
+    P.strict_fences = 0;
     P.oob = const_cast<int32_t *>(oob);
     P.seeds_dev = seeds;
     hipLaunchKernelGGL((loss_main_kernel<false, true>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
@@ -716,11 +824,10 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
     if (ws_bytes < ws_layout(nb, K, N, g, c)) return DVSOF_ENOSPACE;
     P.start = start;
     P.stop = stop;
-    bind_ws(P, ws, nb);
+    bind_ws(P, ws, nb, terms, loss_out, w, loss_scale);
     P.oob = oob;
     P.seeds_dev = nullptr;
     for (int i = 0; i < 3; ++i) P.seeds_host[i] = w[i] / (float)K * loss_scale;
-    DVSOF_HIP_TRY(hipMemsetAsync(oob, 0, sizeof(int32_t) * (size_t)K * N, st));
     if (images) {
         float *levels[DVSOF_MAX_SCALES];
         int hs[DVSOF_MAX_SCALES], wss[DVSOF_MAX_SCALES];
@@ -737,7 +844,7 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
     }
     hipLaunchKernelGGL((loss_main_kernel<true, true>), dim3(nb), dim3(NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
-    return finalize_launch(P, terms, loss_out, w, loss_scale, 0, st);
+    return DVSOF_OK;
 }
 }  // namespace
 

@@ -95,19 +95,25 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t, const
 }  // extern "C"
 
 // ===========================================================================
-// v2: LDS-staged voxel tiles.
-//   pass 1 (vox_bucket_kernel): coalesced read of the five event columns;
-//     every workgroup ranks its 1024 events per tile in an LDS histogram,
-//     reserves a range in each touched tile's bucket with ONE global atomic
-//     per (workgroup, tile) and writes compact 8-byte records
-//     {local pixel | lower bin | sign, fraction}.  Buckets have a fixed
-//     capacity (2x the mean + slack); events that do not fit go to an overflow
-//     list (none for well-spread data, all remain correct otherwise).
+// v2: LDS-staged voxel tiles, TWO launches, no memset, no zero-fill pass.
+//   pass 1 (vox_bucket_kernel): coalesced read of the event columns (int64
+//     wire columns or the 9 B/event compact columns); every workgroup ranks
+//     its events per tile in an LDS histogram (cleared and scanned only over
+//     the tile range its events touch), reserves a range in each touched
+//     tile's bucket with ONE global atomic per (workgroup, tile) and writes
+//     8-byte records {local pixel | lower bin | sign, fraction (exact f32)}.
+//     Buckets have a fixed capacity (2x the mean + slack); events that do not
+//     fit go to an overflow list (none for well-spread data).
 //   pass 2 (vox_tile_kernel): one workgroup per (sample, 32x32 tile): zero the
-//     [C][32][32] tile in LDS, ds_add_f32 the bucket's records, store the tile
-//     with coalesced rows.  No zero-fill pass, no global float atomics.
-//   pass 3 (vox_overflow_kernel): overflow records -> global atomics (after
-//     pass 2, which overwrites the grid).
+//     [C][32][32] tile in LDS, ds_add_f32 the bucket's records, then the
+//     overflow records that belong to this tile (the list is empty unless the
+//     events pile up in a few tiles), store the tile with coalesced rows.
+//     No global float atomics at all.
+//   The control words (bucket cursors, overflow count, finished-tile count)
+//   are SELF-CLEANING: every tile workgroup zeroes its cursor after reading
+//   it, the last one to finish zeroes the two counters.  A workspace whose
+//   control region was zero before a call is zero again after it; the caller
+//   says so with DVSOF_VOX_WS_CLEAN and no memset is enqueued.
 // Integer parts (bin0 / lin0) are computed exactly as in v1 (bit-exact vs the
 // oracle); float sums differ from v1 only in accumulation order.
 // ===========================================================================
@@ -134,8 +140,9 @@ struct VoxV2 {
     int B, C, H, W, TX, TY, ntile, cap;
     int32_t *cursor;      // [ntile] events reserved per tile (may exceed cap)
     int32_t *ovf_count;   // [1]
+    int32_t *done;        // [1] tile workgroups finished
     uint2 *records;       // [ntile][cap]
-    int4 *ovf;            // [n]  {lin_lo, lin_hi, bits(w0), bits(w1)}
+    int4 *ovf;            // [n]  {tile, key, bits(frac), 0}
     int64_t ovf_cap;
     float *out;
     int32_t *bin0;
@@ -146,14 +153,17 @@ template <int EPT>
 __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
 {
     extern __shared__ int sh[];          // hist[ntile], base[ntile]
+    __shared__ int s_lo, s_hi;
     int *hist = sh, *base = sh + P.ntile;
-    for (int i = threadIdx.x; i < P.ntile; i += NT) hist[i] = 0;
+    if (threadIdx.x == 0) {
+        s_lo = P.ntile;
+        s_hi = -1;
+    }
     __syncthreads();
     const int64_t e0 = ((int64_t)blockIdx.x * NT) * EPT + threadIdx.x;
     int tile[EPT], rank[EPT];
     unsigned key[EPT];
     float frac[EPT];
-    int64_t lin[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const int64_t i = e0 + (int64_t)k * NT;   // coalesced across the workgroup
@@ -193,16 +203,41 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
                     if (!zero) tile[k] = ((int)b * P.TY + ty) * P.TX + tx;
                     key[k] = (unsigned)(((int)yi - ty * VT) * VT + ((int)xi - tx * VT)) |
                              ((unsigned)c0 << 10) | (neg ? 0x80000000u : 0u);
-                    if (!zero) rank[k] = atomicAdd(&hist[tile[k]], 1);
                 }
             }
-            lin[k] = l;
             if (P.bin0) P.bin0[i] = c0;
             if (P.lin0) P.lin0[i] = l;
         }
     }
+    // tile range of this workgroup's events (events arrive grouped by sample,
+    // so this is one or two samples' tiles out of ntile)
+    {
+        int lo = P.ntile, hi = -1;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+            if (tile[k] >= 0) {
+                lo = min(lo, tile[k]);
+                hi = max(hi, tile[k]);
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off, kWave));
+            hi = max(hi, __shfl_xor(hi, off, kWave));
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0 && hi >= 0) {
+            atomicMin(&s_lo, lo);
+            atomicMax(&s_hi, hi);
+        }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < P.ntile; i += NT) {
+    const int t_lo = s_lo, t_hi = s_hi;
+    for (int i = t_lo + (int)threadIdx.x; i <= t_hi; i += NT) hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+        if (tile[k] >= 0) rank[k] = atomicAdd(&hist[tile[k]], 1);
+    __syncthreads();
+    for (int i = t_lo + (int)threadIdx.x; i <= t_hi; i += NT) {
         const int c = hist[i];
         base[i] = c ? atomicAdd(&P.cursor[i], c) : 0;
     }
@@ -215,15 +250,17 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
             P.records[(size_t)tile[k] * P.cap + pos] = make_uint2(key[k], __float_as_uint(frac[k]));
         } else {
             const int o = atomicAdd(P.ovf_count, 1);
-            if (o < P.ovf_cap) {
-                const float p = (key[k] & 0x80000000u) ? -1.f : 1.f;
-                const int c0 = (int)((key[k] >> 10) & 0x3ff);
-                const float w1 = (c0 + 1 < P.C) ? p * frac[k] : 0.f;
-                P.ovf[o] = make_int4((int)(lin[k] & 0xffffffff), (int)(lin[k] >> 32),
-                                     __float_as_int(p * (1.f - frac[k])), __float_as_int(w1));
-            }
+            if (o < P.ovf_cap) P.ovf[o] = make_int4(tile[k], (int)key[k], __float_as_int(frac[k]), 0);
         }
     }
+}
+
+__device__ __forceinline__ void tile_add(float *tl, unsigned key, float f, int C)
+{
+    const int pix = key & 0x3ff, c0 = (key >> 10) & 0x3ff;
+    const float p = (key & 0x80000000u) ? -1.f : 1.f;
+    atomicAdd(&tl[c0 * VT * VT + pix], p * (1.f - f));
+    if (c0 + 1 < C) atomicAdd(&tl[(c0 + 1) * VT * VT + pix], p * f);
 }
 
 __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
@@ -233,15 +270,19 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
     const int tx = tile % P.TX, ty = (tile / P.TX) % P.TY, b = tile / (P.TX * P.TY);
     const int nel = P.C * VT * VT;
     for (int i = threadIdx.x; i < nel; i += NT) tl[i] = 0.f;
-    __syncthreads();
     const int cnt = min(P.cursor[tile], P.cap);
+    const int64_t novf = min((int64_t)*P.ovf_count, P.ovf_cap);
+    __syncthreads();
+    if (threadIdx.x == 0) P.cursor[tile] = 0;       // self-cleaning control words
     const uint2 *rec = P.records + (size_t)tile * P.cap;
     for (int i = threadIdx.x; i < cnt; i += NT) {
         const uint2 r = rec[i];
-        const int pix = r.x & 0x3ff, c0 = (r.x >> 10) & 0x3ff;
-        const float p = (r.x & 0x80000000u) ? -1.f : 1.f, f = __uint_as_float(r.y);
-        atomicAdd(&tl[c0 * VT * VT + pix], p * (1.f - f));
-        if (c0 + 1 < P.C) atomicAdd(&tl[(c0 + 1) * VT * VT + pix], p * f);
+        tile_add(tl, r.x, __uint_as_float(r.y), P.C);
+    }
+    // events that did not fit their bucket (skewed inputs only)
+    for (int64_t i = threadIdx.x; i < novf; i += NT) {
+        const int4 r = P.ovf[i];
+        if (r.x == tile) tile_add(tl, (unsigned)r.y, __int_as_float(r.z), P.C);
     }
     __syncthreads();
     const int y0 = ty * VT, x0 = tx * VT;
@@ -250,18 +291,10 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
         const int y = y0 + ly, x = x0 + lx;
         if (y < P.H && x < P.W) P.out[(((size_t)b * P.C + c) * P.H + y) * P.W + x] = tl[i];
     }
-}
-
-__global__ __launch_bounds__(NT) void vox_overflow_kernel(const VoxV2 P)
-{
-    const int64_t cnt = min((int64_t)*P.ovf_count, P.ovf_cap);
-    const size_t plane = (size_t)P.H * P.W;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * NT) {
-        const int4 r = P.ovf[i];
-        const int64_t lin = ((int64_t)r.y << 32) | (uint32_t)r.x;
-        atomicAdd(&P.out[lin], __int_as_float(r.z));
-        const float w1 = __int_as_float(r.w);
-        if (w1 != 0.f) atomicAdd(&P.out[lin + plane], w1);
+    // the last tile to finish (every tile has read ovf_count by then) clears the counters
+    if (threadIdx.x == 0 && atomicAdd(P.done, 1) == P.ntile - 1) {
+        *P.ovf_count = 0;
+        *P.done = 0;
     }
 }
 
@@ -280,9 +313,41 @@ bool v2_plan(int64_t n, int B, int C, int H, int W, VoxV2 &P)
     return true;
 }
 
+size_t v2_control_bytes(const VoxV2 &P) { return (((size_t)P.ntile + 2) * 4 + 255) / 256 * 256; }
+
 size_t v2_bytes(const VoxV2 &P, int64_t n)
 {
-    return ((size_t)P.ntile + 64) * 4 + (size_t)P.ntile * P.cap * 8 + (size_t)n * 16 + 256;
+    return v2_control_bytes(P) + (size_t)P.ntile * P.cap * 8 + (size_t)n * 16 + 256;
+}
+
+// control words first (that is the region DVSOF_VOX_WS_CLEAN speaks about)
+void v2_bind(VoxV2 &P, void *workspace)
+{
+    unsigned char *w = (unsigned char *)workspace;
+    P.cursor = (int32_t *)w;
+    P.ovf_count = P.cursor + P.ntile;
+    P.done = P.ovf_count + 1;
+    w += v2_control_bytes(P);
+    P.records = (uint2 *)w;
+    w += (size_t)P.ntile * P.cap * 8;
+    P.ovf = (int4 *)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+}
+
+int v2_launch(const VoxV2 &P, int flags, hipStream_t st)
+{
+    if (!(flags & DVSOF_VOX_WS_CLEAN))
+        DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, v2_control_bytes(P), st));
+    const int64_t n = P.n;
+    if (n >= EPT8_FROM)
+        hipLaunchKernelGGL(vox_bucket_kernel<8>, dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT),
+                           (size_t)P.ntile * 8, st, P);
+    else
+        hipLaunchKernelGGL(vox_bucket_kernel<4>, dim3((unsigned)((n + NT * 4 - 1) / (NT * 4))), dim3(NT),
+                           (size_t)P.ntile * 8, st, P);
+    DVSOF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), (size_t)P.C * VT * VT * 4, st, P);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
 }
 
 }  // namespace
@@ -320,23 +385,23 @@ size_t dvsof_voxelize_workspace_bytes(int64_t n_events, int B, int C, int H, int
     return v2_bytes(P, n_events);
 }
 
+size_t dvsof_voxelize_control_bytes(int64_t n_events, int B, int C, int H, int W)
+{
+    VoxV2 P;
+    if (n_events < 4096 || !v2_plan(n_events, B, C, H, W, P)) return 0;
+    return v2_control_bytes(P);
+}
+
 int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t, const int64_t *pol,
                          const int64_t *sample, int64_t n, const float *t0, const float *t1, int B,
                          int C, int H, int W, float *out, int32_t *bin0, int64_t *lin0,
-                         void *workspace, size_t workspace_bytes, void *stream)
+                         void *workspace, size_t workspace_bytes, int flags, void *stream)
 {
     VoxV2 P;
     if (n < 4096 || !workspace || !v2_plan(n, B, C, H, W, P) || workspace_bytes < v2_bytes(P, n))
         return dvsof_voxelize_fwd(x, y, t, pol, sample, n, t0, t1, B, C, H, W, out, bin0, lin0, stream);
     if (!out || !t0 || !t1 || !x || !y || !t || !pol || !sample) return DVSOF_EINVAL;
-    hipStream_t st = as_stream(stream);
-    unsigned char *w = (unsigned char *)workspace;
-    P.cursor = (int32_t *)w;
-    P.ovf_count = P.cursor + P.ntile;
-    w += ((size_t)P.ntile + 64) * 4;
-    P.records = (uint2 *)w;
-    w += (size_t)P.ntile * P.cap * 8;
-    P.ovf = (int4 *)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+    v2_bind(P, workspace);
     P.enc = 0;
     P.x16 = P.y16 = nullptr;
     P.p8 = nullptr;
@@ -344,27 +409,14 @@ int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t, con
     P.x = x; P.y = y; P.pol = pol; P.sample = sample; P.t = t; P.t0 = t0; P.t1 = t1;
     P.n = n; P.B = B; P.C = C; P.H = H; P.W = W;
     P.out = out; P.bin0 = bin0; P.lin0 = lin0;
-    // cursor[ntile] + ovf_count, rounded up to 64 B (one fill kernel, no tail)
-    DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, (((size_t)P.ntile + 1) * 4 + 63) / 64 * 64, st));
-    if (n >= EPT8_FROM)
-        hipLaunchKernelGGL(vox_bucket_kernel<8>, dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT),
-                           (size_t)P.ntile * 8, st, P);
-    else
-        hipLaunchKernelGGL(vox_bucket_kernel<4>, dim3((unsigned)((n + NT * 4 - 1) / (NT * 4))), dim3(NT),
-                           (size_t)P.ntile * 8, st, P);
-    DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), (size_t)C * VT * VT * 4, st, P);
-    DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_overflow_kernel, dim3(64), dim3(NT), 0, st, P);
-    DVSOF_LAUNCH_CHECK();
-    return DVSOF_OK;
+    return v2_launch(P, flags, as_stream(stream));
 }
 
 int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
                            const uint8_t *polarity, const int64_t *sample_event_offsets, int64_t n,
                            const float *t0, const float *t1, int B, int C, int H, int W, float *out,
                            int32_t *bin0, int64_t *lin0, void *workspace, size_t workspace_bytes,
-                           void *stream)
+                           int flags, void *stream)
 {
     if (!out || B < 1 || C < 1 || H < 1 || W < 1 || n < 0 || !t0 || !t1) return DVSOF_EINVAL;
     hipStream_t st = as_stream(stream);
@@ -382,33 +434,14 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
         DVSOF_LAUNCH_CHECK();
         return dvsof_voxelize_fwd(wx, wy, t, wp, wsmp, n, t0, t1, B, C, H, W, out, bin0, lin0, stream);
     }
-    unsigned char *w = (unsigned char *)workspace;
-    P.cursor = (int32_t *)w;
-    P.ovf_count = P.cursor + P.ntile;
-    w += ((size_t)P.ntile + 64) * 4;
-    P.records = (uint2 *)w;
-    w += (size_t)P.ntile * P.cap * 8;
-    P.ovf = (int4 *)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+    v2_bind(P, workspace);
     P.enc = 1;
     P.x16 = x; P.y16 = y; P.p8 = polarity; P.ev_off = sample_event_offsets;
     P.x = P.y = P.pol = P.sample = nullptr;
     P.t = t; P.t0 = t0; P.t1 = t1;
     P.n = n; P.B = B; P.C = C; P.H = H; P.W = W;
     P.out = out; P.bin0 = bin0; P.lin0 = lin0;
-    // cursor[ntile] + ovf_count, rounded up to 64 B (one fill kernel, no tail)
-    DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, (((size_t)P.ntile + 1) * 4 + 63) / 64 * 64, st));
-    if (n >= EPT8_FROM)
-        hipLaunchKernelGGL(vox_bucket_kernel<8>, dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT),
-                           (size_t)P.ntile * 8, st, P);
-    else
-        hipLaunchKernelGGL(vox_bucket_kernel<4>, dim3((unsigned)((n + NT * 4 - 1) / (NT * 4))), dim3(NT),
-                           (size_t)P.ntile * 8, st, P);
-    DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), (size_t)C * VT * VT * 4, st, P);
-    DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_overflow_kernel, dim3(64), dim3(NT), 0, st, P);
-    DVSOF_LAUNCH_CHECK();
-    return DVSOF_OK;
+    return v2_launch(P, flags, st);
 }
 
 }  // extern "C"

@@ -30,6 +30,36 @@ def get_count_image(events, imsize, device='cuda'):
     return out.cpu().numpy().astype(np.uint32).astype(np.uint64)
 
 
+WS_CLEAN = 1       # DVSOF_VOX_WS_CLEAN
+_WORKSPACES = {}
+
+
+def _workspace(n, B, C, H, W, device):
+    """-> (tensor, nbytes, flags).  The tiled voxeliser's control words clean
+    up after themselves (include/dvsof.h), so a workspace is zero-filled ONCE
+    and then reused by every call of the same shape on the same stream: no
+    memset launch per call.  One workspace per (shape, device, stream): calls
+    on one stream are ordered, different streams never share one."""
+    lib = _lib.lib()
+    nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
+    control = lib.dvsof_voxelize_control_bytes(n, B, C, H, W)
+    if control == 0:        # thread-per-event kernel: plain scratch
+        return (torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device),
+                nbytes, 0)
+    if torch.cuda.is_current_stream_capturing():
+        # a graph owns its memory: fresh scratch + the memset node
+        return (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes, 0)
+    key = (nbytes, control, str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        if len(_WORKSPACES) >= 8:       # a handful of shapes is the normal case
+            _WORKSPACES.clear()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ws[:control].zero_()
+        _WORKSPACES[key] = ws
+    return ws, nbytes, WS_CLEAN
+
+
 def voxelize(events, t0, t1, B, C, H, W, debug=False):
     """events: dict of device tensors in the wire format; t0/t1: float32[B].
     -> grid float32 [B,C,H,W] (and bin0 int32[n], lin0 int64[n] if debug)."""
@@ -48,13 +78,12 @@ def voxelize(events, t0, t1, B, C, H, W, debug=False):
         bin0 = torch.empty(max(n, 1), dtype=torch.int32, device=t0.device)
         lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=t0.device)
     lib = _lib.lib()
-    nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=t0.device)
+    ws, nbytes, flags = _workspace(n, B, C, H, W, t0.device)
     _lib.check(lib.dvsof_voxelize_tiled(
         x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(), s.data_ptr(),
         n, t0.contiguous().data_ptr(), t1.contiguous().data_ptr(), B, C, H, W,
         out.data_ptr(), _lib.ptr(bin0), _lib.ptr(lin0), _lib.ptr(ws), nbytes,
-        _lib.stream()), 'dvsof_voxelize_tiled')
+        flags, _lib.stream()), 'dvsof_voxelize_tiled')
     if debug:
         return out, bin0[:n], lin0[:n]
     return out
@@ -90,14 +119,13 @@ def voxelize_compact(events, t0, t1, B, C, H, W, debug=False):
         bin0 = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     lib = _lib.lib()
-    nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    ws, nbytes, flags = _workspace(n, B, C, H, W, dev)
     _lib.check(lib.dvsof_voxelize_encoded(
         x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(),
         off.data_ptr(), n, t0.contiguous().data_ptr(),
         t1.contiguous().data_ptr(), B, C, H, W, out.data_ptr(),
-        _lib.ptr(bin0), _lib.ptr(lin0), ws.data_ptr(), nbytes, _lib.stream()),
-        'dvsof_voxelize_encoded')
+        _lib.ptr(bin0), _lib.ptr(lin0), ws.data_ptr(), nbytes, flags,
+        _lib.stream()), 'dvsof_voxelize_encoded')
     if debug:
         return out, bin0[:n], lin0[:n]
     return out

@@ -62,6 +62,7 @@ int dvsof_count_image(const int64_t *x, const int64_t *y, int64_t n_events,
  * format (utils/dataset.py:961-1020): int64 x,y,polarity,sample_index and
  * float32 window-relative timestamp.  t0[b], t1[b] are the window of sample b.
  * n_events may be 0 (utils/loss.py:217-240 probes the model that way).
+ * polarity is a SIGN: > 0 adds, < 0 subtracts, 0 contributes nothing.
  * bin0 (int32[n]) / lin0 (int64[n]) are optional debug outputs: the lower
  * temporal bin and the linear index of (b,bin0,y,x), -1 for dropped events.
  */
@@ -72,28 +73,41 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t,
                        int64_t *lin0, void *stream);
 
 /*
- * Same result through LDS-staged voxel tiles: events are bucketed per 32x32
- * tile in one coalesced pass, each tile is accumulated in LDS and stored with
- * plain coalesced writes (no zero-fill, no global float atomics unless a
- * bucket overflows).  Falls back to dvsof_voxelize_fwd for tiny inputs or when
+ * Same result through LDS-staged voxel tiles, two launches: events are
+ * bucketed per 32x32 tile in one coalesced pass, each tile is accumulated in
+ * LDS and stored with plain coalesced writes (no zero-fill pass, no global
+ * float atomics).  Falls back to dvsof_voxelize_fwd for tiny inputs or when
  * the workspace is missing/too small.  Integer parts are identical; float
  * sums differ only in accumulation order.
+ *
+ * Workspace contract: the first dvsof_voxelize_control_bytes() bytes are
+ * control words (bucket cursors, counters).  They must be ZERO when the call
+ * starts executing and the call leaves them zero again (the kernels clean up
+ * after themselves).  flags:
+ *   0                   the call enqueues a memset of the control words first
+ *   DVSOF_VOX_WS_CLEAN  the caller guarantees they are zero (zero-filled once,
+ *                       then only used by calls of this family, one at a time
+ *                       in stream order): no memset is enqueued
  */
+#define DVSOF_VOX_WS_CLEAN 1
 size_t dvsof_voxelize_workspace_bytes(int64_t n_events, int B, int C, int H,
                                       int W);
+/* 0 when the thread-per-event kernel serves this size (no control words) */
+size_t dvsof_voxelize_control_bytes(int64_t n_events, int B, int C, int H,
+                                    int W);
 int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t,
                          const int64_t *polarity, const int64_t *sample_index,
                          int64_t n_events, const float *t0, const float *t1,
                          int B, int C, int H, int W, float *out, int32_t *bin0,
                          int64_t *lin0, void *workspace,
-                         size_t workspace_bytes, void *stream);
+                         size_t workspace_bytes, int flags, void *stream);
 
 /*
  * The same grid from the reference's ENCODED event columns (encode_batch,
  * utils/dataset.py:240-305: int16 x, int16 y, float32 timestamp, bool
  * polarity = 9 bytes/event instead of 44).  sample_event_offsets[B+1] = index
  * of the first event of every sample (from events_per_element /
- * elements_per_sample).  Workspace: dvsof_voxelize_workspace_bytes.
+ * elements_per_sample).  Workspace and flags: as dvsof_voxelize_tiled.
  */
 int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
                            const uint8_t *polarity,
@@ -101,7 +115,7 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
                            int64_t n_events, const float *t0, const float *t1,
                            int B, int C, int H, int W, float *out,
                            int32_t *bin0, int64_t *lin0, void *workspace,
-                           size_t workspace_bytes, void *stream);
+                           size_t workspace_bytes, int flags, void *stream);
 
 /* ------------------------------------------------------------------ *
  * Data augmentation on the device: horizontal

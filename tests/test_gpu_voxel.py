@@ -102,3 +102,49 @@ def test_voxelize_tiled_overflow_and_ragged():
     # thousands of +-1 weights pile up on 6 pixels: tolerance scales with the count
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=5e-3)
     assert float(got[1].abs().max()) == 0.0
+
+
+def test_tiled_workspace_cleans_up_after_itself():
+    """The control words of the tiled path (bucket cursors, overflow / finished
+    counters) are zeroed by the kernels themselves: the workspace is
+    zero-filled once (voxel._workspace) and every later call runs without a
+    memset -- also after a call that overflowed its buckets."""
+    from dvs_of_training_framework_amd import voxel
+    B, C, H, W, n = 2, 5, 64, 96, 20000
+    rng = np.random.default_rng(4)
+    spread = synthetic.make_events(rng, B, H, W, n)
+    crowded = {k: v.copy() for k, v in spread.items()}
+    crowded['x'][:] = 7
+    crowded['y'][:] = 9                      # every event in one pixel: overflow list
+    t0 = torch.zeros(B, device='cuda')
+    t1 = torch.full((B,), synthetic.WINDOW, device='cuda')
+    z, w = np.zeros(B, np.float32), np.full(B, synthetic.WINDOW, np.float32)
+    voxel._WORKSPACES.clear()
+    for ev in (spread, crowded, spread, crowded, spread):
+        want, _, lin0 = orc.voxelize(ev, z, w, B, C, H, W)
+        got, _, glin = voxel.voxelize(dev_events(ev), t0, t1, B, C, H, W, debug=True)
+        assert np.array_equal(glin.cpu().numpy(), lin0)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=5e-3)
+    assert len(voxel._WORKSPACES) == 1
+    ws = next(iter(voxel._WORKSPACES.values()))
+    control = voxel._lib.lib().dvsof_voxelize_control_bytes(B * n, B, C, H, W)
+    assert control > 0 and int(ws[:control].to(torch.int32).abs().sum()) == 0
+
+
+def test_polarity_is_a_sign_in_both_kernels():
+    """VOXEL_SPEC: only the sign of the polarity counts (0 contributes nothing,
+    |p| > 1 counts once) -- the thread-per-event kernel (n < 4096) and the
+    tiled path agree with the oracle and so with each other."""
+    from dvs_of_training_framework_amd.voxel import voxelize
+    B, C, H, W = 2, 3, 32, 64
+    z, w = np.zeros(B, np.float32), np.full(B, synthetic.WINDOW, np.float32)
+    t0, t1 = torch.from_numpy(z).cuda(), torch.from_numpy(w).cuda()
+    for n in (1000, 6000):                    # v1 kernel | tiled path
+        rng = np.random.default_rng(n)
+        ev = synthetic.make_events(rng, B, H, W, n)
+        ev['polarity'] = rng.integers(-3, 4, B * n).astype(np.int64)   # includes 0, +-2, +-3
+        want, bin0, lin0 = orc.voxelize(ev, z, w, B, C, H, W)
+        got, gbin, glin = voxelize(dev_events(ev), t0, t1, B, C, H, W, debug=True)
+        assert np.array_equal(gbin.cpu().numpy(), bin0)
+        assert np.array_equal(glin.cpu().numpy(), lin0)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-5, rtol=1e-3)
