@@ -89,13 +89,20 @@ __device__ __forceinline__ bool out_of_border(float gx, float gy)
 constexpr int NGROUP = 8;   // doubles per group record: 7 sums + pad
 constexpr int NW = NT / kWave;
 
-// Publish / observe protocol of the folded reduction.  Records are written
-// with agent-scope atomic stores (write-through to the memory side, visible
-// to every XCD once acknowledged: s_waitcnt vmcnt(0)) and read back with
-// agent-scope atomic loads; the arrival counters are agent-scope RMWs.  With
-// strict_fences the RMW is additionally bracketed by the memory model's
-// agent-scope release (before) and acquire (after, in the workgroup that goes
-// on to read) fences -- the textbook fence-reduction pattern.
+// Publish / observe protocol of the folded reduction.  Everything one
+// workgroup hands to another goes through agent-scope ATOMIC accesses only:
+// records are written with agent-scope atomic stores (the backend emits them
+// write-through, sc1: they do not linger in this XCD's non-coherent L2) and
+// read with agent-scope atomic loads; the arrival counters are agent-scope
+// RMWs.  Ordering: the publishing wave waits until its stores are acknowledged
+// (s_waitcnt vmcnt(0)) before it bumps the counter -- the agent-scope release
+// sequence of the LLVM AMDGPU memory model for gfx942/gfx950 is exactly
+// {buffer_wbl2 sc1; s_waitcnt vmcnt(0)}, and the wbl2 only exists to write
+// back NON-atomic dirty lines, of which this protocol publishes none.  The
+// reader's loads are atomic too, so no acquire-side invalidate is needed.
+// With strict_fences (DVSOF_LOSS_STRICT=1) the RMW is bracketed by the
+// model's full agent-scope release / acquire fences instead; same results
+// (tests run both), 2.3x the kernel time (bind_ws).
 __device__ __forceinline__ int arrive(int *counter, int strict)
 {
     if (strict) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -206,13 +213,32 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     const size_t hw = (size_t)h * w;
     const float *U = S.flow + (size_t)n * 2 * hw;
 
-    for (int i = tid; i < LH * LW; i += NT) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
-        const bool in = (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
-        const size_t o = (size_t)gy * w + gx;
-        sF[0][ly][lx] = in ? U[o] : 0.f;
-        sF[1][ly][lx] = in ? U[hw + o] : 0.f;
+    // flow tile + halo -> LDS.  Fixed trip count, loads first: the 2*FILL loads
+    // of a thread are in flight together (a rolled loop makes FILL dependent
+    // load -> wait -> ds_write round trips, and a workgroup's life is a chain of
+    // such round trips: at batch 8 every workgroup is resident at once and the
+    // kernel takes exactly as long as one workgroup does)
+    {
+        constexpr int FILL = (LH * LW + NT - 1) / NT;
+        float fu[FILL], fv[FILL];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int i = tid + it * NT;
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+            const bool in = (i < LH * LW) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
+            const size_t o = in ? (size_t)gy * w + gx : 0;
+            fu[it] = in ? U[o] : 0.f;
+            fv[it] = in ? U[hw + o] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int i = tid + it * NT;
+            if (i < LH * LW) {
+                (&sF[0][0][0])[i] = fu[it];
+                (&sF[1][0][0])[i] = fv[it];
+            }
+        }
     }
     const float *I0 = S.frames + (size_t)P.start[n] * hw;
     const float *I1 = S.frames + (size_t)P.stop[n] * hw;
@@ -640,10 +666,14 @@ void bind_ws(Params &P, void *ws, int nb, float *terms, float *loss_out, const f
     P.loss_out = loss_out;
     for (int i = 0; i < 3; ++i) P.wts[i] = w ? w[i] : 0.f;
     P.loss_scale = loss_scale;
-    // DVSOF_LOSS_RELAXED=1: counters without the agent-scope release/acquire
-    // fences (write-through record stores + s_waitcnt only; see arrive())
-    static const bool relaxed = getenv("DVSOF_LOSS_RELAXED") != nullptr;
-    P.strict_fences = relaxed ? 0 : 1;
+    // DVSOF_LOSS_STRICT=1: additionally bracket the arrival counters with the
+    // memory model's agent-scope release / acquire fences (see arrive()).
+    // Measured on MI355X: the release fence in EVERY workgroup (buffer_wbl2 of
+    // an L2 full of freshly written gradients) takes the fused loss from
+    // 126 to 291 us at batch 64 -- so the default publishes the few words the
+    // reduction needs with write-through atomic stores instead.
+    static const bool strict = getenv("DVSOF_LOSS_STRICT") != nullptr;
+    P.strict_fences = strict ? 1 : 0;
 }
 
 // Pyramid plan: fused single launch when the level sizes are non-decreasing

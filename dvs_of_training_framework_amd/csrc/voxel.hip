@@ -139,8 +139,9 @@ struct VoxV2 {
     int64_t n;
     int B, C, H, W, TX, TY, ntile, cap;
     int32_t *cursor;      // [ntile] events reserved per tile (may exceed cap)
-    int32_t *ovf_count;   // [1]
-    int32_t *done;        // [1] tile workgroups finished
+    int32_t *ovf_count;   // [1] overflow records
+    int32_t *ovf_tiles;   // [1] tiles whose bucket overflowed
+    int32_t *done;        // [1] of those, finished
     uint2 *records;       // [ntile][cap]
     int4 *ovf;            // [n]  {tile, key, bits(frac), 0}
     int64_t ovf_cap;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
         if (pos < P.cap) {
             P.records[(size_t)tile[k] * P.cap + pos] = make_uint2(key[k], __float_as_uint(frac[k]));
         } else {
+            if (pos == P.cap) atomicAdd(P.ovf_tiles, 1);     // exactly one event per full bucket
             const int o = atomicAdd(P.ovf_count, 1);
             if (o < P.ovf_cap) P.ovf[o] = make_int4(tile[k], (int)key[k], __float_as_int(frac[k]), 0);
         }
@@ -269,20 +271,34 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
     const int tile = blockIdx.x;
     const int tx = tile % P.TX, ty = (tile / P.TX) % P.TY, b = tile / (P.TX * P.TY);
     const int nel = P.C * VT * VT;
+    const int reserved = P.cursor[tile];
     for (int i = threadIdx.x; i < nel; i += NT) tl[i] = 0.f;
-    const int cnt = min(P.cursor[tile], P.cap);
-    const int64_t novf = min((int64_t)*P.ovf_count, P.ovf_cap);
+    const int cnt = min(reserved, P.cap);
     __syncthreads();
     if (threadIdx.x == 0) P.cursor[tile] = 0;       // self-cleaning control words
     const uint2 *rec = P.records + (size_t)tile * P.cap;
-    for (int i = threadIdx.x; i < cnt; i += NT) {
-        const uint2 r = rec[i];
-        tile_add(tl, r.x, __uint_as_float(r.y), P.C);
+    // 4 record loads in flight per thread (a rolled loop is one dependent
+    // memory round trip per iteration)
+    for (int i0 = 0; i0 < cnt; i0 += 4 * NT) {
+        uint2 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT + (int)threadIdx.x;
+            r[u] = i < cnt ? rec[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * NT + (int)threadIdx.x < cnt) tile_add(tl, r[u].x, __uint_as_float(r[u].y), P.C);
     }
-    // events that did not fit their bucket (skewed inputs only)
-    for (int64_t i = threadIdx.x; i < novf; i += NT) {
-        const int4 r = P.ovf[i];
-        if (r.x == tile) tile_add(tl, (unsigned)r.y, __int_as_float(r.z), P.C);
+    // events that did not fit this tile's bucket (skewed inputs only): they
+    // are on the overflow list among those of the other full buckets
+    const bool spilled = reserved > P.cap;
+    if (spilled) {
+        const int64_t novf = min((int64_t)*P.ovf_count, P.ovf_cap);
+        for (int64_t i = threadIdx.x; i < novf; i += NT) {
+            const int4 r = P.ovf[i];
+            if (r.x == tile) tile_add(tl, (unsigned)r.y, __int_as_float(r.z), P.C);
+        }
     }
     __syncthreads();
     const int y0 = ty * VT, x0 = tx * VT;
@@ -291,9 +307,11 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
         const int y = y0 + ly, x = x0 + lx;
         if (y < P.H && x < P.W) P.out[(((size_t)b * P.C + c) * P.H + y) * P.W + x] = tl[i];
     }
-    // the last tile to finish (every tile has read ovf_count by then) clears the counters
-    if (threadIdx.x == 0 && atomicAdd(P.done, 1) == P.ntile - 1) {
+    // the last SPILLED tile to finish (every one of them has read the list by
+    // then) clears the overflow words; well-spread inputs never get here
+    if (spilled && threadIdx.x == 0 && atomicAdd(P.done, 1) == *P.ovf_tiles - 1) {
         *P.ovf_count = 0;
+        *P.ovf_tiles = 0;
         *P.done = 0;
     }
 }
@@ -313,7 +331,7 @@ bool v2_plan(int64_t n, int B, int C, int H, int W, VoxV2 &P)
     return true;
 }
 
-size_t v2_control_bytes(const VoxV2 &P) { return (((size_t)P.ntile + 2) * 4 + 255) / 256 * 256; }
+size_t v2_control_bytes(const VoxV2 &P) { return (((size_t)P.ntile + 3) * 4 + 255) / 256 * 256; }
 
 size_t v2_bytes(const VoxV2 &P, int64_t n)
 {
@@ -326,7 +344,8 @@ void v2_bind(VoxV2 &P, void *workspace)
     unsigned char *w = (unsigned char *)workspace;
     P.cursor = (int32_t *)w;
     P.ovf_count = P.cursor + P.ntile;
-    P.done = P.ovf_count + 1;
+    P.ovf_tiles = P.ovf_count + 1;
+    P.done = P.ovf_count + 2;
     w += v2_control_bytes(P);
     P.records = (uint2 *)w;
     w += (size_t)P.ntile * P.cap * 8;
