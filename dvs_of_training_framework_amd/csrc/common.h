@@ -47,3 +47,23 @@ __device__ __forceinline__ float charb_val(float d)
     const float s = fmaf(d, d, 1e-6f);
     return s * __builtin_amdgcn_exp2f(-0.55f * __builtin_amdgcn_logf(s));
 }
+
+// Two Charbonnier evaluations at once (the two flow channels of one pair):
+// the arithmetic around the two v_log / v_exp maps to packed-f32 VALU ops
+// (v_pk_fma_f32 / v_pk_mul_f32: two floats per lane per issue).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Charb2 {
+    f32x2 val, der;
+};
+__device__ __forceinline__ Charb2 charbonnier2(f32x2 d)
+{
+    const f32x2 eps = {1e-6f, 1e-6f};
+    const f32x2 s = __builtin_elementwise_fma(d, d, eps);
+    f32x2 l = {__builtin_amdgcn_logf(s.x), __builtin_amdgcn_logf(s.y)};
+    l *= -0.55f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(l.x), __builtin_amdgcn_exp2f(l.y)};
+    Charb2 c;
+    c.val = s * e;
+    c.der = (d * 0.9f) * e;
+    return c;
+}

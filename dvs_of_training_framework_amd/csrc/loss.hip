@@ -44,6 +44,7 @@ struct ScaleDev {
     int h, w;
     int tiles_x, tiles_per_sample, block_begin;
     float half_w, half_h;        // (w-1)/2, (h-1)/2 (utils/loss.py:152-154)
+    float rcp_half_w, rcp_half_h;  // correctly rounded reciprocals (0 when the side is 1)
     float k_smooth[3];           // 1/(4*count) for ->, v, diagonal crops
     float k_photo;               // 1/(N*h*w)
     double c_smooth[3];          // crop element counts (utils/loss.py:77-85)
@@ -74,12 +75,25 @@ __device__ __forceinline__ int find_scale(const Params &P, int bid)
     return k;
 }
 
+// a / b correctly rounded from r = RN(1/b): q0 = RN(a r), e = a - b q0 (exact,
+// one fma), q = RN(q0 + e r).  Markstein's theorem: correctly rounded whenever
+// r is the correctly rounded reciprocal and b's significand is not all ones,
+// barring over/underflow -- b = (size-1)/2 of an image side here, |a| < 2^24.
+// The compiler's IEEE expansion of `/` is ~10 instructions (div_scale x2, rcp,
+// 4 fma, div_fmas, div_fixup); this is 3, with the same bits.
+__device__ __forceinline__ float div_exact(float a, float b, float r)
+{
+    const float q0 = a * r;
+    const float e = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e, r, q0);
+}
+
 // utils/loss.py:150-156 in fp32, op for op (IEEE division).
 __device__ __forceinline__ void warp_grid(const ScaleDev &S, int x, int y, float u,
                                           float v, float &gx, float &gy)
 {
-    gx = ((float)x + u) / S.half_w - 1.f;
-    gy = ((float)y + v) / S.half_h - 1.f;
+    gx = div_exact((float)x + u, S.half_w, S.rcp_half_w) - 1.f;
+    gy = div_exact((float)y + v, S.half_h, S.rcp_half_h) - 1.f;
 }
 __device__ __forceinline__ bool out_of_border(float gx, float gy)
 {  // utils/loss.py:92-94 (strict)
@@ -272,6 +286,8 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     // 5*NP loads are in flight together instead of NP dependent round trips
     bool valid[NP], oobv[NP];
     float uu[NP], vv[NP], axv[NP], ayv[NP], nwv[NP], nev[NP], swv[NP], sev[NP], prv[NP];
+    float m00[NP], m01[NP], m10[NP], m11[NP];
+    const int xc = min(x, w - 1);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int ly = ly0 + j, y = ty0 + ly;
@@ -289,14 +305,29 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
         ayv[j] = iy - fy0;
         const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f);
         const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
-        const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x0 + 1 >= 0) & (x0 + 1 < w);
-        const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y0 + 1 >= 0) & (y0 + 1 < h);
-        const float *r0 = I1 + (ptrdiff_t)y0 * w + x0;
-        nwv[j] = (valid[j] & vy0 & vx0) ? r0[0] : 0.f;
-        nev[j] = (valid[j] & vy0 & vx1) ? r0[1] : 0.f;
-        swv[j] = (valid[j] & vy1 & vx0) ? r0[w] : 0.f;
-        sev[j] = (valid[j] & vy1 & vx1) ? r0[w + 1] : 0.f;
-        prv[j] = valid[j] ? I0[(size_t)y * w + x] : 0.f;
+        // unconditional loads from clamped addresses, zero padding as a 0/1
+        // factor afterwards: no exec-mask branch per tap, all loads in flight
+        const float vx0 = ((x0 >= 0) & (x0 < w)) ? 1.f : 0.f, vx1 = ((x0 >= -1) & (x0 + 1 < w)) ? 1.f : 0.f;
+        const float vy0 = ((y0 >= 0) & (y0 < h)) ? 1.f : 0.f, vy1 = ((y0 >= -1) & (y0 + 1 < h)) ? 1.f : 0.f;
+        const float mv = valid[j] ? 1.f : 0.f;
+        m00[j] = mv * vy0 * vx0;
+        m01[j] = mv * vy0 * vx1;
+        m10[j] = mv * vy1 * vx0;
+        m11[j] = mv * vy1 * vx1;
+        const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
+        const int ya = min(max(y0, 0), h - 1) * w, yb = min(max(y0 + 1, 0), h - 1) * w;
+        nwv[j] = I1[ya + xa];
+        nev[j] = I1[ya + xb];
+        swv[j] = I1[yb + xa];
+        sev[j] = I1[yb + xb];
+        prv[j] = I0[min(y, h - 1) * w + xc];
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        nwv[j] *= m00[j];
+        nev[j] *= m01[j];
+        swv[j] *= m10[j];
+        sev[j] *= m11[j];
     }
 
     // left-edge column (x = tx0 - 1) derivatives the strip's lane 0 needs:
@@ -348,65 +379,73 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     // d2 = rho'(F[r+1][x+1] - F[r][x]), d3 = rho'(F[r][x+1] - F[r+1][x]).
     // Pixel (r, x) is the SECOND operand of its own d0, d1, d2, the FIRST of
     // d0(r, x-1), d1(r-1, x), d2(r-1, x-1), d3(r, x-1), the SECOND of d3(r-1, x).
+    // Branch-free: the LDS halo is zero-filled outside the frame, so every pair
+    // can be evaluated and then multiplied by its 0/1 validity.  The two flow
+    // channels of a pair go through the arithmetic together (packed f32).
     {
-        const bool xin = x < w, xr = x + 1 < w;
-        bool rin[6];                       // rows -1..4 of the strip inside the frame
+        const float mx = x < w ? 1.f : 0.f, mxr = x + 1 < w ? 1.f : 0.f;
+        float mrow[6];                     // rows -1..4 of the strip inside the frame
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int y = ty0 + ly0 + r - 1;
-            rin[r] = (y >= 0) & (y < h);
+            mrow[r] = ((y >= 0) & (y < h)) ? 1.f : 0.f;
         }
+        f32x2 a0[6], a1[6];                // columns x, x+1; rows -1..4; (u, v)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float a0[6], a1[6];            // columns x, x+1; rows -1..4
+        for (int r = 0; r < 6; ++r) {
+            a0[r] = f32x2{sF[0][ly0 + r][lane + 1], sF[1][ly0 + r][lane + 1]};
+            a1[r] = f32x2{sF[0][ly0 + r][lane + 2], sF[1][ly0 + r][lane + 2]};
+        }
+        f32x2 d0[5], d1[5], d2[5], d3[5];  // index r + 1
+        f32x2 s1 = {0.f, 0.f}, s2 = s1, s3 = s1, s4 = s1;
+        d0[0] = s1;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                a0[r] = sF[c][ly0 + r][lane + 1];
-                a1[r] = sF[c][ly0 + r][lane + 2];
+        for (int r = 0; r < 5; ++r) {
+            const bool own = r >= 1;       // anchor row of this strip: sums count
+            const float m0 = mrow[r] * mxr, mv = mrow[r] * mrow[r + 1];
+            const float m1 = mv * mx, m2 = mv * mxr;
+            if (own) {
+                const Charb2 q = charbonnier2(a1[r] - a0[r]);
+                if (FWD) s1 += q.val * m0;
+                d0[r] = q.der * m0;
             }
-            float d0[5], d1[5], d2[5], d3[5];      // index r + 1
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const bool own = r >= 1;           // anchor row of this strip: sums count
-                const bool p0 = rin[r] & xr, p1 = rin[r] & rin[r + 1] & xin,
-                           p2 = rin[r] & rin[r + 1] & xr;
-                d0[r] = d1[r] = d2[r] = d3[r] = 0.f;
-                if (own && p0) {
-                    const Charb q = charbonnier(a1[r] - a0[r]);
-                    if (FWD) acc[1] += q.val;
-                    d0[r] = q.der;
-                }
-                if (p1) {
-                    const Charb q = charbonnier(a0[r + 1] - a0[r]);
-                    if (FWD && own) acc[2] += q.val;
-                    d1[r] = q.der;
-                }
-                if (p2) {
-                    const Charb q = charbonnier(a1[r + 1] - a0[r]);
-                    if (FWD && own) acc[3] += q.val;
-                    d2[r] = q.der;
-                    const Charb z = charbonnier(a1[r] - a0[r + 1]);
-                    if (FWD && own) acc[4] += z.val;
-                    d3[r] = z.der;
-                }
+            const Charb2 q1 = charbonnier2(a0[r + 1] - a0[r]);
+            const Charb2 q2 = charbonnier2(a1[r + 1] - a0[r]);
+            const Charb2 q3 = charbonnier2(a1[r] - a0[r + 1]);
+            if (FWD && own) {
+                s2 += q1.val * m1;
+                s3 += q2.val * m2;
+                s4 += q3.val * m2;
             }
-            if (BWD) {
+            d1[r] = q1.der * m1;
+            d2[r] = q2.der * m2;
+            d3[r] = q3.der * m2;
+        }
+        if (FWD) {
+            acc[1] = s1.x + s1.y;
+            acc[2] = s2.x + s2.y;
+            acc[3] = s3.x + s3.y;
+            acc[4] = s4.x + s4.y;
+        }
+        if (BWD) {
+            const float k0 = S.k_smooth[0] * seed[0], k1 = S.k_smooth[1] * seed[0],
+                        k2 = S.k_smooth[2] * seed[0];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const int r = j + 1;
-                    // from the column to the left: lane - 1, or the edge row for lane 0
-                    float in0 = __shfl_up(d0[r], 1, kWave), in2 = __shfl_up(d2[r - 1], 1, kWave),
-                          in3 = __shfl_up(d3[r], 1, kWave);
-                    if (lane == 0) {
-                        in0 = sE[wave][c][j];
-                        in2 = sE[wave][c][4 + j];
-                        in3 = sE[wave][c][8 + j];
-                    }
-                    float g = S.k_smooth[0] * (in0 - d0[r]) + S.k_smooth[1] * (d1[r - 1] - d1[r]) +
-                              S.k_smooth[2] * ((in2 - d2[r]) + (in3 - d3[r - 1]));
-                    g *= seed[0];
-                    if (c == 0) gu[j] += g; else gv[j] += g;
+            for (int j = 0; j < NP; ++j) {
+                const int r = j + 1;
+                // from the column to the left: lane - 1, or the edge row for lane 0
+                f32x2 in0 = {__shfl_up(d0[r].x, 1, kWave), __shfl_up(d0[r].y, 1, kWave)};
+                f32x2 in2 = {__shfl_up(d2[r - 1].x, 1, kWave), __shfl_up(d2[r - 1].y, 1, kWave)};
+                f32x2 in3 = {__shfl_up(d3[r].x, 1, kWave), __shfl_up(d3[r].y, 1, kWave)};
+                if (lane == 0) {
+                    in0 = f32x2{sE[wave][0][j], sE[wave][1][j]};
+                    in2 = f32x2{sE[wave][0][4 + j], sE[wave][1][4 + j]};
+                    in3 = f32x2{sE[wave][0][8 + j], sE[wave][1][8 + j]};
                 }
+                const f32x2 g = (in0 - d0[r]) * k0 + (d1[r - 1] - d1[r]) * k1 +
+                                ((in2 - d2[r]) + (in3 - d3[r - 1])) * k2;
+                gu[j] += g.x;
+                gv[j] += g.y;
             }
         }
     }
@@ -628,6 +667,10 @@ int build_params(const dvsof_loss_scale_t *sc, int K, int N, Params &P, int &tot
         begin += N * S.tiles_per_sample;
         S.half_w = (float)((w - 1) / 2.0);
         S.half_h = (float)((h - 1) / 2.0);
+        // RN(1/b) via double: the double quotient is within 2^-53 relative of
+        // 1/b and b = m/2 with m < 2^24 an integer, so no double-rounding tie
+        S.rcp_half_w = w > 1 ? (float)(1.0 / (double)S.half_w) : 0.f;
+        S.rcp_half_h = h > 1 ? (float)(1.0 / (double)S.half_h) : 0.f;
         S.c_smooth[0] = (double)N * 2 * h * (w - 1);
         S.c_smooth[1] = (double)N * 2 * (h - 1) * w;
         S.c_smooth[2] = (double)N * 2 * (h - 1) * (w - 1);
