@@ -129,6 +129,11 @@ def add_train_arguments(parser):           # utils/options.py:204-302
                         help='matrix-core operand type of the conv stack: exact f32, '
                              'bf16 hi+lo split (three products, ~f32 accuracy) or bf16; '
                              'storage and accumulation are f32 in every mode')
+    parser.add_argument('--compact-events', dest='compact_events',
+                        action='store_true',
+                        help='with --preprocessed-dataset-path: hand raw '
+                             'events to the device voxeliser in their 9 B/event '
+                             'encoded columns (no int64 wire columns)')
     parser.add_argument('--synthetic', action='store_true',
                         help='train on seeded synthetic batches (no dataset)')
     parser.add_argument('--synthetic-events', dest='synthetic_events',

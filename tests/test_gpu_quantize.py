@@ -85,3 +85,53 @@ def test_quantized_batch_trains_like_the_raw_batch():
     lb.backward()
     g = [p.grad for p in model.predictor.parameters()]
     assert all(x is not None and bool(torch.isfinite(x).all()) for x in g)
+
+
+def test_training_from_a_preprocessed_dataset(tmp_path):
+    """tests/dataset/test_encoding.py:315-360 restated: a collated batch is
+    encoded, written as <n>.hdf5, read back by PreprocessedDataloader and
+    trained on.  The decoded (wire-format) batches and the compact 9 B/event
+    batches give the same loss (to the voxeliser's summation order)."""
+    from dvs_of_training_framework_amd import encoding, hdf5io
+    if not hdf5io.available():
+        pytest.skip('libhdf5 not found')
+    import train_flownet as tf
+    from dvs_of_training_framework_amd.loss import init_losses
+    from dvs_of_training_framework_amd.net import Model
+    from dvs_of_training_framework_amd.preprocessed import (PreprocessedDataloader,
+                                                             write_encoded_batch)
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch, train
+    B, H, W, C = 4, 64, 64, 5
+    b = synthetic.to_torch(synthetic.make_batch(31, B, H, W, 6000))
+    aug = {'idx': torch.arange(B), 'sequence_length': torch.ones(B, dtype=torch.short),
+           'collapse_length': torch.ones(B, dtype=torch.short),
+           'box': torch.tensor([[0, 0, H, W]] * B), 'angle': torch.zeros(B),
+           'is_flip': torch.zeros(B, dtype=torch.bool)}
+    write_encoded_batch(tmp_path / '0.hdf5', encoding.encode_batch(
+        b['events'], b['timestamps'], b['sample_idx'], b['images'], aug, B))
+    torch.manual_seed(1)
+    model = Model('cuda', event_representation_depth=C)
+    ev = init_losses((H, W), 2, model, 'cuda', sequence_length=1)
+    losses = {}
+    for compact in (False, True):
+        dl = PreprocessedDataloader(tmp_path, 2, is_raw=True, compact=compact)
+        with torch.no_grad():
+            loss, _, _ = process_minibatch(model, next(dl), FakeTimer(), 'cuda', True, ev,
+                                           [0.5, 1, 1])
+        losses[compact] = float(loss)
+    assert abs(losses[True] - losses[False]) <= 1e-5 * abs(losses[False])
+    # two optimizer steps over the cyclic loader (4 samples, batch 2, compact events)
+    args = tf.parse_args(['-m', str(tmp_path / 'model'), '--optimizer', 'ADAM', '-bs', '2', '-mbs',
+                          '2', '--height', str(H), '--width', str(W), '-ne', '3',
+                          '--event-representation-depth', str(C), '-d', 'cuda:0'])
+    optimizer, scheduler = tf.construct_train_tools(args, model)
+    seen = []
+
+    class Log:
+        def add_scalar(self, t, v, x):
+            if t == 'General/Train loss':
+                seen.append((x, v))
+    train(model, 'cuda', PreprocessedDataloader(tmp_path, 2, is_raw=True, compact=True), optimizer,
+          3, scheduler, Log(), ev, timers=FakeTimer())
+    assert [x for x, _ in seen] == [2, 4, 6] and all(np.isfinite(v) for _, v in seen)

@@ -123,6 +123,23 @@ class SyntheticLoader:
                 a.synthetic_events, seq_len=seq))
 
 
+class _Strided:
+    """Every rank takes one batch and skips the other ranks' (the loader is
+    sequential and cyclic: rank r starts r batches in, set_index above)."""
+
+    def __init__(self, loader, world):
+        self.loader, self.world = loader, world
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        batch = next(self.loader)
+        for _ in range(self.world - 1):
+            next(self.loader)
+        return batch
+
+
 class _NullLogger:
     def add_scalar(self, *a, **k):
         pass
@@ -162,6 +179,21 @@ def main(argv=None):
     if args.synthetic:
         loader = SyntheticLoader(args, rank,
                                  args.training_steps * args.accum_step)
+    elif getattr(args, 'preprocessed_dataset_path', None) is not None:
+        # utils/dataloader.py:89-100: the preprocessed (encoded / quantized)
+        # dataset; --compact-events keeps raw events in their 9 B/event columns
+        # all the way to the device voxeliser.  Ranks read disjoint strides.
+        from dvs_of_training_framework_amd.preprocessed import \
+            PreprocessedDataloader
+        loader = PreprocessedDataloader(
+            path=args.preprocessed_dataset_path, batch_size=args.mbs,
+            is_raw=args.is_raw, cache_dir=getattr(args, 'cache_dir', None),
+            cache_size=getattr(args, 'cache_size', 0),
+            process_only_once=False,
+            compact=getattr(args, 'compact_events', False))
+        loader.set_index(rank * args.mbs)
+        if world > 1:
+            loader = _Strided(loader, world)
     else:
         try:    # dropped into the reference tree: use its data pipeline
             from utils.dataloader import get_trainset_params, get_dataloader, \
