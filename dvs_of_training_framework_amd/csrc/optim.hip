@@ -38,11 +38,22 @@ __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v,
 
 // table: per tensor {p, g, m, v, vmax} pointers and element count; chunk
 // table: (tensor id, chunk index) per workgroup.
+// dyn (optional, device): {lr, lr / (1 - beta1^t), sqrt(1 - beta2^t)} of THIS
+// step.  A step captured in a hipGraph bakes its kernel arguments in; what
+// changes from step to step (learning-rate schedule, bias corrections) then
+// comes from this table, which the host refreshes before every replay.
 __global__ __launch_bounds__(256) void adamw_kernel(const uint64_t *__restrict__ ptrs,
                                                     const int64_t *__restrict__ sizes,
                                                     const int32_t *__restrict__ chunks,
-                                                    const AdamArgs a)
+                                                    const AdamArgs a_in,
+                                                    const float *__restrict__ dyn)
 {
+    AdamArgs a = a_in;
+    if (dyn) {
+        a.lr = dyn[0];
+        a.step_size = dyn[1];
+        a.bc2_sqrt = dyn[2];
+    }
     const int t = chunks[2 * blockIdx.x], c = chunks[2 * blockIdx.x + 1];
     float *p = (float *)ptrs[5 * t + 0];
     const float *g = (const float *)ptrs[5 * t + 1];
@@ -103,7 +114,36 @@ int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes, const int32_t *
     a.bc2_sqrt = (float)sqrt(bc2);
     a.amsgrad = amsgrad;
     hipLaunchKernelGGL(adamw_kernel, dim3(num_chunks), dim3(256), 0, as_stream(stream), ptrs, sizes,
-                       chunks, a);
+                       chunks, a, (const float *)nullptr);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+void dvsof_adamw_dynamic(float lr, float beta1, float beta2, int step, float *host_out3)
+{
+    // the same double-precision bias corrections as dvsof_adamw_step
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    host_out3[0] = lr;
+    host_out3[1] = (float)((double)lr / bc1);
+    host_out3[2] = (float)sqrt(bc2);
+}
+
+int dvsof_adamw_step_dyn(const uint64_t *ptrs, const int64_t *sizes, const int32_t *chunks,
+                         int num_chunks, const float *dyn, float beta1, float beta2, float eps,
+                         float weight_decay, int amsgrad, void *stream)
+{
+    if (!ptrs || !sizes || !chunks || !dyn || num_chunks < 0) return DVSOF_EINVAL;
+    if (num_chunks == 0) return DVSOF_OK;
+    AdamArgs a;
+    a.lr = a.step_size = a.bc2_sqrt = 0.f;   // from dyn
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    a.amsgrad = amsgrad;
+    hipLaunchKernelGGL(adamw_kernel, dim3(num_chunks), dim3(256), 0, as_stream(stream), ptrs, sizes,
+                       chunks, a, dyn);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

@@ -16,6 +16,9 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _lib.register('dvsof_adamw_chunk_elems', _i, [])
 _lib.register('dvsof_adamw_step', _i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f,
                                        _i, _i, _vp])
+_lib.register('dvsof_adamw_dynamic', None, [_f, _f, _f, _i, ctypes.POINTER(_f)])
+_lib.register('dvsof_adamw_step_dyn', _i, [_vp, _vp, _vp, _i, _vp, _f, _f, _f,
+                                           _f, _i, _vp])
 _lib.register('dvsof_radam_step', _i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f,
                                        _i, _f, _i, _i, _f, _vp])
 _lib.register('dvsof_grad_centralize', _i, [_vp, _i, _i, _vp])
@@ -103,12 +106,14 @@ class _FusedBase(torch.optim.Optimizer):
         for p in plist:
             assert _dense(p) and not p.grad.is_sparse
         steps = set()
+        frozen = getattr(self, '_frozen', False)    # captured step: advance() counts
         for p in plist:
             st = self._state(p)
-            st['step'] = int(st['step']) + 1
+            if not frozen:
+                st['step'] = int(st['step']) + 1
             steps.add(st['step'])
         assert len(steps) == 1, 'tensors of one group step together'
-        self._launch(group, self._table(key, plist), steps.pop(), plist)
+        self._launch(group, self._table(key, plist), max(steps.pop(), 1), plist)
 
     # ---- update fused into the backward ------------------------------------
     def fuse_into_backward(self, predictor, flush_at=None):
@@ -182,11 +187,52 @@ class FusedAdamW(_FusedBase):
     def _launch(self, group, tables, step, plist):
         t_ptrs, t_sizes, t_chunks, n = tables
         b1, b2 = group['betas']
+        dyn = getattr(self, '_dyn', None)
+        if dyn is not None:     # captured step: lr and bias corrections from the device table
+            gi = next(i for i, g in enumerate(self.param_groups) if g is group)
+            _lib.check(_lib.lib().dvsof_adamw_step_dyn(
+                t_ptrs.data_ptr(), t_sizes.data_ptr(), t_chunks.data_ptr(), n,
+                dyn['device'][gi].data_ptr(), float(b1), float(b2),
+                float(group['eps']), float(group['weight_decay']),
+                1 if group['amsgrad'] else 0, _lib.stream()),
+                'dvsof_adamw_step_dyn')
+            return
         _lib.check(_lib.lib().dvsof_adamw_step(
             t_ptrs.data_ptr(), t_sizes.data_ptr(), t_chunks.data_ptr(), n,
             float(group['lr']), float(b1), float(b2), float(group['eps']),
             float(group['weight_decay']), step,
             1 if group['amsgrad'] else 0, _lib.stream()), 'dvsof_adamw_step')
+
+    # ---- a step captured in a hipGraph (capture.CapturedTrainStep) ---------
+    def begin_capture(self, device):
+        """From now on ``step()`` enqueues the dyn-table kernel and leaves the
+        step counters alone (a capture enqueues nothing; ``advance`` counts)."""
+        ng = len(self.param_groups)
+        self._dyn = {'device': torch.zeros(ng, 4, dtype=torch.float32,
+                                           device=device),
+                     'host': torch.zeros(ng, 4, dtype=torch.float32).pin_memory()}
+        self._frozen = True
+
+    def advance(self):
+        """Before every replay: count the step and refresh {lr, lr/bc1,
+        sqrt(bc2)} of every group (one small async H2D copy)."""
+        host = self._dyn['host']
+        buf = (ctypes.c_float * 3)()
+        for gi, group in enumerate(self.param_groups):
+            steps = set()
+            for p in group['params']:
+                st = self._state(p)
+                st['step'] = int(st['step']) + 1
+                steps.add(st['step'])
+            assert len(steps) == 1
+            b1, b2 = group['betas']
+            _lib.lib().dvsof_adamw_dynamic(float(group['lr']), float(b1),
+                                           float(b2), steps.pop(), buf)
+            host[gi, 0], host[gi, 1], host[gi, 2] = buf[0], buf[1], buf[2]
+        self._dyn['device'].copy_(host, non_blocking=True)
+
+    def end_capture(self):
+        self._dyn, self._frozen = None, False
 
 
 class FusedRAdam(_FusedBase):

@@ -424,6 +424,23 @@ int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes,
                      float beta1, float beta2, float eps, float weight_decay,
                      int step, int amsgrad, void *stream);
 
+/*
+ * The same update for a step that is CAPTURED in a hipGraph (the train loop of
+ * utils/training.py:138-167 replayed as one graph launch): kernel arguments
+ * are frozen at capture, so what changes per step -- the scheduled learning
+ * rate (LambdaLR, train_flownet.py:91-109) and the bias corrections -- is read
+ * from `dyn`, device float[3] = {lr, lr/(1-beta1^t), sqrt(1-beta2^t)}.
+ * dvsof_adamw_dynamic fills a HOST float[3] with exactly the values
+ * dvsof_adamw_step would use (the caller copies it to `dyn` before each replay),
+ * so both entry points give bit-identical parameters.
+ */
+void dvsof_adamw_dynamic(float lr, float beta1, float beta2, int step,
+                         float *host_out3);
+int dvsof_adamw_step_dyn(const uint64_t *ptrs, const int64_t *sizes,
+                         const int32_t *chunks, int num_chunks,
+                         const float *dyn, float beta1, float beta2, float eps,
+                         float weight_decay, int amsgrad, void *stream);
+
 
 /*
  * Fused multi-tensor RAdam / Ranger step for one parameter group.  Replaces

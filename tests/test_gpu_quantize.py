@@ -92,7 +92,7 @@ def test_training_from_a_preprocessed_dataset(tmp_path):
     encoded, written as <n>.hdf5, read back by PreprocessedDataloader and
     trained on.  The decoded (wire-format) batches and the compact 9 B/event
     batches give the same loss (to the voxeliser's summation order)."""
-    from dvs_of_training_framework_amd import encoding, hdf5io
+    from dvs_of_training_framework_amd import encoding, hdf5io, synthetic
     if not hdf5io.available():
         pytest.skip('libhdf5 not found')
     import train_flownet as tf
