@@ -1,0 +1,141 @@
+"""One training step as ONE hipGraph launch.
+
+The reference's loop body (utils/training.py:138-167: batch to device, model,
+loss, ``backward()``, ``optimizer.step()``) is ~130 kernel launches here; at
+batch 8 the host needs ~2 ms to enqueue what the GPU runs in ~3 ms.
+``CapturedTrainStep`` records that body once -- voxelise, predictor forward,
+fused loss, the two-stream backward, AdamW -- for a fixed batch signature
+(batch size, frame size, event capacity) and replays it:
+
+  * inputs live in static device buffers; a batch is copied in, its events
+    padded to the capacity with x = y = -1 (the voxeliser drops them);
+  * the graph holds KERNELS ONLY: no memset / memcpy nodes (the voxeliser's
+    control words clean up after themselves, the loss needs no zero-fill), all
+    scratch comes from the graph's private pool, gradient buckets and
+    optimizer tables are the persistent ones the eager warm-up step made;
+  * what changes per step is read from device memory: the scheduled learning
+    rate and Adam's bias corrections (``FusedAdamW.advance`` refreshes a
+    3-float table before each replay), so LambdaLR keeps working.
+
+Results are bit-identical to the eager step (same kernels, same order, same
+arguments; tests/test_gpu_capture.py).  Not captured: gradient accumulation
+over micro-batches and the data-parallel exchange (``train`` keeps those
+eager).
+"""
+import torch
+
+from .loss import unit_backward
+from .timer import FakeTimer
+from .training import TermReadback, process_minibatch
+
+EVENT_KEYS = ('x', 'y', 'timestamp', 'polarity', 'element_index',
+              'sample_index')
+
+
+def _pow2_at_least(n, floor=4096):
+    return max(floor, 1 << max(int(n) - 1, 1).bit_length())
+
+
+class CapturedTrainStep:
+    def __init__(self, model, evaluator, optimizer, weights, device,
+                 example_batch, event_capacity=None):
+        """example_batch: a batch of the signature to capture (wire-format
+        events; its tensors may live on the host).  The constructor runs ONE
+        eager, validated step on it (host-side assertions, lazy allocations,
+        optimizer state and tables) -- a real optimizer step -- then captures."""
+        assert hasattr(optimizer, 'begin_capture'), \
+            'the captured step needs optim.FusedAdamW (device-resident lr table)'
+        self.model, self.evaluator, self.optimizer = model, evaluator, optimizer
+        self.weights, self.device = list(weights), torch.device(device)
+        ev = example_batch['events']
+        n = ev['x'].numel()
+        self.capacity = event_capacity or _pow2_at_least(n)
+        assert n <= self.capacity
+        dev = self.device
+        self.static = {
+            'events': {k: torch.zeros(self.capacity, dtype=ev[k].dtype, device=dev)
+                       for k in EVENT_KEYS if k in ev},
+            'timestamps': torch.zeros_like(example_batch['timestamps'], device=dev),
+            'sample_idx': torch.zeros_like(example_batch['sample_idx'], device=dev),
+            'images': torch.zeros_like(example_batch['images'], device=dev),
+            'size': int(example_batch['size']),
+        }
+        self.signature = self._signature(example_batch)
+        self._load(example_batch)
+        # eager step: validates the layout, allocates buckets / state / tables
+        model.train()
+        optimizer.zero_grad(set_to_none=True)
+        loss, terms, tags = process_minibatch(
+            model, self.static, FakeTimer(), dev, True, evaluator, self.weights)
+        unit_backward(loss)
+        optimizer.step()
+        if hasattr(model, 'strict'):
+            # the index vectors of the validated layout are built now, eagerly
+            # (inside the capture they would become graph-owned ATen launches)
+            model.strict = False
+            model._select(self.static['timestamps'], self.static['sample_idx'],
+                          self.static['size'])
+        self.tags = list(tags)
+        self.first_loss, self.first_terms = loss.detach().clone(), terms
+        terms.host()
+        torch.cuda.synchronize(dev)
+        # capture (p.grad stays the bucket views: same pointers as the tables)
+        optimizer.begin_capture(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            loss, terms, _ = process_minibatch(
+                model, self.static, FakeTimer(), dev, True, evaluator,
+                self.weights)
+            unit_backward(loss)
+            optimizer.step()
+        self.loss = loss.detach()
+        self._terms = terms._terms      # _Terms: .packed is the [3,K] tensor
+        self.replays = 0
+
+    @staticmethod
+    def _signature(batch):
+        return (int(batch['size']), tuple(batch['images'].shape),
+                tuple(batch['timestamps'].shape))
+
+    def fits(self, batch):
+        return self._signature(batch) == self.signature and \
+            batch['events']['x'].numel() <= self.capacity
+
+    def _load(self, batch):
+        ev, st = batch['events'], self.static['events']
+        n = ev['x'].numel()
+        for k, buf in st.items():
+            buf[:n].copy_(ev[k], non_blocking=True)
+        if n < self.capacity:
+            st['x'][n:] = -1
+            st['y'][n:] = -1
+            st['sample_index'][n:] = 0
+        for k in ('timestamps', 'sample_idx', 'images'):
+            self.static[k].copy_(batch[k], non_blocking=True)
+
+    def __call__(self, batch):
+        """-> (loss, terms): 0-dim tensor and a TermReadback, both reading the
+        graph's static outputs (valid until the next call)."""
+        assert self.fits(batch), 'batch does not match the captured signature'
+        self._load(batch)
+        self.optimizer.advance()
+        self.graph.replay()
+        self.replays += 1
+        return self.loss, TermReadback(self._terms)
+
+    def eager_step(self, batch, timers=None):
+        """A batch that does not fit the captured signature: the same step,
+        eagerly, on the same persistent gradient buckets."""
+        opt = self.optimizer
+        opt.end_capture()
+        opt.zero_grad(set_to_none=True)
+        loss, terms, tags = process_minibatch(
+            self.model, batch, timers or FakeTimer(), self.device, True,
+            self.evaluator, self.weights)
+        unit_backward(loss)
+        opt.step()          # p.grad stays: the graph's tables point at the buckets
+        opt.begin_capture(self.device)
+        return loss, terms, tags
+
+    def close(self):
+        self.optimizer.end_capture()

@@ -9,7 +9,10 @@ import torch.nn as nn
 
 from .net import Model
 
+import os
+
 script_dir = osp.dirname(osp.realpath(__file__))
+_GRAPH_SYNC = os.environ.get('DVSOF_GRAPH_SYNC') == '1'
 
 
 class OpticalFlow:
@@ -60,8 +63,14 @@ class OpticalFlow:
                      sidx=sidx.clone(), graph=None, flow=None)
             self._graphs[B] = g
         assert ts.numel() == g['ts'].numel()
-        if g.get('done') is not None:
-            g['done'].synchronize()       # the static inputs are free again
+        # Replays, and the copies into the static inputs between them, are
+        # ordered on one stream; no host synchronisation is needed.  The graph
+        # holds kernels only (the voxeliser's control words clean up after
+        # themselves, so there is no memset node; its workspace is the one the
+        # eager warm-up call made).  DVSOF_GRAPH_SYNC=1 restores the round-1
+        # behaviour (wait for the previous replay) as a diagnostic.
+        if _GRAPH_SYNC and g.get('done') is not None:
+            g['done'].synchronize()
         for k, v in ev.items():
             g['ev'][k][:n].copy_(v)
         g['ev']['x'][n:] = -1
@@ -81,14 +90,10 @@ class OpticalFlow:
                 g['flow'] = self._net(g['ev'], g['ts'], g['sidx'], self.imsize,
                                       batch_size=B)[0]
             g['graph'] = graph
-        # one replay in flight at a time: launching the graph again while the
-        # previous replay is still running faulted on ROCm 7.2 (write to a
-        # read-only page); __call__ copies the result to the host anyway
-        if g.get('done') is not None:
-            g['done'].synchronize()
         g['graph'].replay()
-        g['done'] = torch.cuda.Event()
-        g['done'].record()
+        if _GRAPH_SYNC:
+            g['done'] = torch.cuda.Event()
+            g['done'].record()
         return g['flow']
 
     def _collate(self, events, start, stop):

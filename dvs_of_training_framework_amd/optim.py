@@ -106,7 +106,7 @@ class _FusedBase(torch.optim.Optimizer):
         for p in plist:
             assert _dense(p) and not p.grad.is_sparse
         steps = set()
-        frozen = getattr(self, '_frozen', False)    # captured step: advance() counts
+        frozen = getattr(self, '_use_dyn', False)   # captured step: advance() counts
         for p in plist:
             st = self._state(p)
             if not frozen:
@@ -187,12 +187,11 @@ class FusedAdamW(_FusedBase):
     def _launch(self, group, tables, step, plist):
         t_ptrs, t_sizes, t_chunks, n = tables
         b1, b2 = group['betas']
-        dyn = getattr(self, '_dyn', None)
-        if dyn is not None:     # captured step: lr and bias corrections from the device table
+        if getattr(self, '_use_dyn', False):     # captured step: lr and bias corrections from the device table
             gi = next(i for i, g in enumerate(self.param_groups) if g is group)
             _lib.check(_lib.lib().dvsof_adamw_step_dyn(
                 t_ptrs.data_ptr(), t_sizes.data_ptr(), t_chunks.data_ptr(), n,
-                dyn['device'][gi].data_ptr(), float(b1), float(b2),
+                self._dyn[gi].data_ptr(), float(b1), float(b2),
                 float(group['eps']), float(group['weight_decay']),
                 1 if group['amsgrad'] else 0, _lib.stream()),
                 'dvsof_adamw_step_dyn')
@@ -206,19 +205,21 @@ class FusedAdamW(_FusedBase):
     # ---- a step captured in a hipGraph (capture.CapturedTrainStep) ---------
     def begin_capture(self, device):
         """From now on ``step()`` enqueues the dyn-table kernel and leaves the
-        step counters alone (a capture enqueues nothing; ``advance`` counts)."""
-        ng = len(self.param_groups)
-        self._dyn = {'device': torch.zeros(ng, 4, dtype=torch.float32,
-                                           device=device),
-                     'host': torch.zeros(ng, 4, dtype=torch.float32).pin_memory()}
-        self._frozen = True
+        step counters alone (capturing enqueues nothing; ``advance`` counts).
+        The table is allocated once: a captured graph keeps its address."""
+        if getattr(self, '_dyn', None) is None:
+            self._dyn = torch.zeros(len(self.param_groups), 4,
+                                    dtype=torch.float32, device=device)
+        self._use_dyn = True
 
     def advance(self):
         """Before every replay: count the step and refresh {lr, lr/bc1,
-        sqrt(bc2)} of every group (one small async H2D copy)."""
-        host = self._dyn['host']
+        sqrt(bc2)} of every group.  The host values travel through a pageable
+        staging copy (complete when the call returns), so the next call may
+        overwrite them while this step is still queued."""
+        rows = []
         buf = (ctypes.c_float * 3)()
-        for gi, group in enumerate(self.param_groups):
+        for group in self.param_groups:
             steps = set()
             for p in group['params']:
                 st = self._state(p)
@@ -228,11 +229,12 @@ class FusedAdamW(_FusedBase):
             b1, b2 = group['betas']
             _lib.lib().dvsof_adamw_dynamic(float(group['lr']), float(b1),
                                            float(b2), steps.pop(), buf)
-            host[gi, 0], host[gi, 1], host[gi, 2] = buf[0], buf[1], buf[2]
-        self._dyn['device'].copy_(host, non_blocking=True)
+            rows.append([buf[0], buf[1], buf[2], 0.0])
+        self._dyn.copy_(torch.tensor(rows, dtype=torch.float32))
 
     def end_capture(self):
-        self._dyn, self._frozen = None, False
+        """Back to eager steps (the table stays: a graph may still use it)."""
+        self._use_dyn = False
 
 
 class FusedRAdam(_FusedBase):

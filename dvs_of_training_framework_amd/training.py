@@ -243,7 +243,7 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
           evaluator, weights=[0.5, 1, 1], is_raw=True, accumulation_steps=1,
           timers=None, hooks={}, init_step=0, init_samples_passed=0,
           max_events_per_batch: int = 350000, reducer=None,
-          log_every: int = 1):
+          log_every: int = 1, capture=False):
     """Semantics of utils/training.py:89-235: ``accumulation_steps``
     micro-batches per optimizer step (each loss scaled by 1/accumulation_steps),
     batches above ``max_events_per_batch`` events are skipped and not counted,
@@ -252,6 +252,11 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
 
     reducer:   parallel.GradReducer (data parallelism)
     log_every: write scalars every n-th optimizer step (1 = the reference)
+    capture:   replay the loop body as one hipGraph launch per step
+               (capture.CapturedTrainStep) once a batch signature has been
+               seen; raw events, no accumulation, no reducer -- anything else,
+               and any batch that does not fit the captured signature, runs
+               eagerly as before
     """
     if timers is None:
         on_gpu = torch.device(device).type == 'cuda'
@@ -259,6 +264,7 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
     clock = _StepClock(init_step, accumulation_steps, num_steps,
                        init_samples_passed)
     sums = ScaleSums()
+    captured = None
     model.train()
     optimizer.zero_grad(set_to_none=True)
 
@@ -278,26 +284,46 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
         if hasattr(optimizer, 'fused_active'):      # optim.fuse_into_backward
             optimizer.fused_active = closes_step
 
-        loss, terms, tags = process_minibatch(
-            model, batch, timers, device, is_raw, evaluator, weights)
-        with _timed(timers, 'backprop'):
-            if accumulation_steps == 1:
-                unit_backward(loss)     # seed 1.0: no fill, no scaling pass
-            else:
-                loss /= accumulation_steps
-                loss.backward()
-        if hasattr(model, 'strict'):
-            model.strict = False        # layout was validated on batch one
+        replayed = False
+        if capture and is_raw and accumulation_steps == 1 and reducer is None \
+                and hasattr(optimizer, 'begin_capture'):
+            if captured is None:
+                from .capture import CapturedTrainStep
+                # its constructor runs this batch's step eagerly, then records
+                captured = CapturedTrainStep(model, evaluator, optimizer,
+                                             weights, device, batch)
+                loss, terms, tags = (captured.first_loss, captured.first_terms,
+                                     captured.tags)
+                replayed = True
+            elif captured.fits(batch):
+                with _timed(timers, 'forward'):
+                    loss, terms = captured(batch)
+                tags, replayed = captured.tags, True
+            else:       # another signature: same step, eagerly
+                loss, terms, tags = captured.eager_step(batch, timers)
+                replayed = True
+        if not replayed:
+            loss, terms, tags = process_minibatch(
+                model, batch, timers, device, is_raw, evaluator, weights)
+            with _timed(timers, 'backprop'):
+                if accumulation_steps == 1:
+                    unit_backward(loss)     # seed 1.0: no fill, no scaling pass
+                else:
+                    loss /= accumulation_steps
+                    loss.backward()
+            if hasattr(model, 'strict'):
+                model.strict = False        # layout was validated on batch one
 
         if not closes_step:
             with _timed(timers, 'logging'):
                 sums.add(loss, terms, tags)
         else:
             with _timed(timers, 'optimizer_step'):
-                if reducer is not None:
-                    reducer.wait()
-                optimizer.step()
-                optimizer.zero_grad(set_to_none=True)
+                if not replayed:        # a captured / replayed step holds the update
+                    if reducer is not None:
+                        reducer.wait()
+                    optimizer.step()
+                    optimizer.zero_grad(set_to_none=True)
             scheduler.step()
             with _timed(timers, 'logging'):
                 wanted = clock.step % log_every == 0
@@ -319,6 +345,8 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
         timers.log(names=list(STAGES) + list(hooks))
         timers('batch_construction').start()
     timers('batch_construction').stop()
+    if captured is not None:
+        captured.close()
 
 
 def validate(model, device, loader, samples_passed, logger, evaluator,

@@ -37,21 +37,25 @@ _WORKSPACES = {}
 def _workspace(n, B, C, H, W, device):
     """-> (tensor, nbytes, flags).  The tiled voxeliser's control words clean
     up after themselves (include/dvsof.h), so a workspace is zero-filled ONCE
-    and then reused by every call of the same shape on the same stream: no
-    memset launch per call.  One workspace per (shape, device, stream): calls
-    on one stream are ordered, different streams never share one."""
+    and then reused by every call of the same shape on that device: no memset
+    launch per call, and a hipGraph capture of the step (capture.py) holds
+    kernels only -- the capture reuses the workspace its eager warm-up call
+    made.  One voxelisation of a given shape at a time per device: calls on
+    one stream are ordered; two streams voxelising the same shape concurrently
+    must not share this cache (pass their own workspace through the C ABI)."""
     lib = _lib.lib()
     nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
     control = lib.dvsof_voxelize_control_bytes(n, B, C, H, W)
     if control == 0:        # thread-per-event kernel: plain scratch
         return (torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device),
                 nbytes, 0)
-    if torch.cuda.is_current_stream_capturing():
-        # a graph owns its memory: fresh scratch + the memset node
-        return (torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes, 0)
-    key = (nbytes, control, str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (nbytes, control, str(device))
     ws = _WORKSPACES.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            # no warm-up call made one: graph-owned scratch + a memset node
+            return (torch.empty(nbytes, dtype=torch.uint8, device=device),
+                    nbytes, 0)
         if len(_WORKSPACES) >= 8:       # a handful of shapes is the normal case
             _WORKSPACES.clear()
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -1,0 +1,155 @@
+"""Child process of tests/test_gpu_capture.py (a GPU fault must not take the
+test runner down): runs one scenario and prints one JSON line.
+
+  train   N training steps eagerly and N as hipGraph replays (no host sync
+          between steps), same seeds / batches / LR schedule: bitwise equality
+  loop    training.train(capture=False) vs train(capture=True): logged scalars
+  infer   OpticalFlow(graph=True): 30 replays back to back WITHOUT reading the
+          result in between, then compared with the eager wrapper
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch  # noqa: E402
+
+from dvs_of_training_framework_amd import synthetic  # noqa: E402
+
+
+def unique_pixel_batch(seed, B, H, W, n):
+    """Every event of a sample on its own pixel: each voxel then receives
+    contributions of ONE event, so the voxeliser's float atomics cannot
+    reorder anything and whole steps are bitwise reproducible."""
+    b = synthetic.make_batch(seed, B, H, W, n)
+    rng = np.random.default_rng(seed + 99)
+    ev = b['events']
+    for s in range(B):
+        m = ev['sample_index'] == s
+        pix = rng.permutation(H * W)[:int(m.sum())]
+        ev['x'][m], ev['y'][m] = pix % W, pix // W
+    return b
+
+
+def make(seed=5, C=5, dtype='f32'):
+    from dvs_of_training_framework_amd.loss import init_losses
+    from dvs_of_training_framework_amd.net import Model
+    from dvs_of_training_framework_amd.optim import FusedAdamW
+    torch.manual_seed(seed)
+    model = Model('cuda', event_representation_depth=C, compute_dtype=dtype)
+    model.train()
+    opt = FusedAdamW(model.predictor.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 0.5 ** (s / 3) if s > 1 else (s + 1) / 2)
+    return model, opt, sched, init_losses
+
+
+def scenario_train():
+    from dvs_of_training_framework_amd.capture import CapturedTrainStep
+    from dvs_of_training_framework_amd.loss import unit_backward
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch
+    B, H, W, steps = 2, 64, 64, 12
+    counts = [4096, 3500, 4096, 2800]
+    batches = [synthetic.to_torch(unique_pixel_batch(70 + i, B, H, W, counts[i % 4]), 'cuda')
+               for i in range(4)]
+
+    def eager():
+        model, opt, sched, init_losses = make()
+        ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+        losses = []
+        for i in range(steps):
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = process_minibatch(model, batches[i % 4], FakeTimer(), 'cuda', True, ev,
+                                           [0.5, 1, 1])
+            unit_backward(loss)
+            model.strict = False
+            opt.step()
+            sched.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return [float(v) for v in losses], [p.detach().clone() for p in model.parameters()]
+
+    def graphed():
+        model, opt, sched, init_losses = make()
+        ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+        step = CapturedTrainStep(model, ev, opt, [0.5, 1, 1], 'cuda', batches[0],
+                                 event_capacity=8192)
+        sched.step()
+        losses = [step.first_loss]
+        terms = None
+        for i in range(1, steps):        # no host sync anywhere in this loop
+            loss, terms = step(batches[i % 4])
+            sched.step()
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+        table = terms.host()
+        step.close()
+        return [float(v) for v in losses], [p.detach().clone() for p in model.parameters()], \
+            table, step.replays
+
+    l_e, w_e = eager()
+    l_g, w_g, table, replays = graphed()
+    l_e2, w_e2 = eager()
+    return {'losses_equal': l_e == l_g, 'weights_equal': all(torch.equal(a, b) for a, b in zip(w_e, w_g)),
+            'eager_reproducible': l_e == l_e2 and all(torch.equal(a, b) for a, b in zip(w_e, w_e2)),
+            'replays': replays, 'loss_first': l_e[0], 'loss_last': l_e[-1], 'graph_last': l_g[-1],
+            'terms_finite': bool(np.isfinite(np.array(table)).all()),
+            'max_weight_diff': max(float((a - b).abs().max()) for a, b in zip(w_e, w_g))}
+
+
+def scenario_loop():
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import train
+    B, H, W = 2, 64, 64
+    data = [unique_pixel_batch(200 + i, B, H, W, 4096 if i % 3 else 3000) for i in range(6)]
+    data[4] = unique_pixel_batch(204, 1, H, W, 4096)        # another signature: runs eagerly
+
+    def run(capture):
+        model, opt, sched, init_losses = make()
+        ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+        rows = []
+
+        class Log:
+            def add_scalar(self, t, v, x):
+                rows.append((t, float(v), x))
+        train(model, 'cuda', (synthetic.to_torch(b) for b in data), opt, 6, sched, Log(), ev,
+              timers=FakeTimer(), capture=capture, max_events_per_batch=10 ** 7)
+        torch.cuda.synchronize()
+        return rows, [p.detach().clone() for p in model.parameters()]
+    r0, w0 = run(False)
+    r1, w1 = run(True)
+    return {'rows_equal': r0 == r1, 'n_rows': len(r0),
+            'weights_equal': all(torch.equal(a, b) for a, b in zip(w0, w1)),
+            'first_diff': next((a, b) for a, b in zip(r0, r1) if a != b) if r0 != r1 else None}
+
+
+def scenario_infer():
+    from dvs_of_training_framework_amd.of import OpticalFlow
+    H = W = 64
+    rng = np.random.default_rng(3)
+
+    def events(n):
+        return [(rng.integers(0, W, n), rng.integers(0, H, n), np.sort(rng.random(n) * 0.04),
+                 rng.integers(0, 2, n) * 2 - 1) for _ in range(2)]
+    torch.manual_seed(4)
+    eager = OpticalFlow((H, W), model=None, event_representation_depth=5)
+    graph = OpticalFlow((H, W), model=None, graph=True, event_representation_depth=5)
+    graph.load_state_dict(eager._net.state_dict())
+    evs = [events(n) for n in (6000, 5000, 6000)]
+    graph(evs[0], [0.0, 0.0], [0.04, 0.04])                 # capture
+    with torch.no_grad():
+        for i in range(30):                                  # replays back to back, unread
+            ev, ts, sidx = graph._collate(evs[i % 3], [0.0, 0.0], [0.04, 0.04])
+            flow = graph._replay(ev, ts, sidx, 2)
+    got = graph._postprocess(flow, False)
+    want = eager(evs[29 % 3], [0.0, 0.0], [0.04, 0.04])
+    return {'max_diff': float(np.abs(got - want).max()), 'peak': float(np.abs(want).max()),
+            'graphs': len(graph._graphs)}
+
+
+if __name__ == '__main__':
+    out = {'train': scenario_train, 'loop': scenario_loop, 'infer': scenario_infer}[sys.argv[1]]()
+    print(json.dumps(out), flush=True)

@@ -1,0 +1,50 @@
+"""hipGraph capture of the training step (SURVEY 8a row a2 deliverable:
+"HIP-graph-capturable step") and of the inference wrapper, replayed back to
+back without host synchronisation.  Every scenario runs in a child process
+(tests/capture_child.py): a GPU fault there fails one test instead of killing
+the runner."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+CHILD = Path(__file__).resolve().parent / 'capture_child.py'
+
+
+def run(scenario):
+    out = subprocess.run([sys.executable, str(CHILD), scenario], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_captured_training_step_is_bit_identical_to_the_eager_step():
+    """12 steps over batches of varying event counts under an LR schedule
+    (warm-up then decay): eager loop vs 1 eager + 11 replays.  Same losses,
+    same weights, bit for bit; the eager loop itself is reproducible."""
+    r = run('train')
+    assert r['eager_reproducible'], r
+    assert r['replays'] == 11 and r['terms_finite']
+    assert r['losses_equal'] and r['weights_equal'], r
+
+
+def test_train_loop_with_capture_logs_the_same_scalars():
+    """training.train(capture=True): same TensorBoard rows and weights as the
+    eager loop, including a batch of another signature in the middle (runs
+    eagerly on the same gradient buckets)."""
+    r = run('loop')
+    assert r['n_rows'] > 0 and r['rows_equal'] and r['weights_equal'], r
+
+
+def test_inference_graph_replays_back_to_back_without_host_sync():
+    """Round 1 synchronised the host before every replay because relaunching
+    the graph while the previous replay was in flight faulted.  The captured
+    graph now holds kernels only (no memset node: the voxeliser's control
+    words are self-cleaning); 30 unread replays in a row must reproduce the
+    eager result."""
+    r = run('infer')
+    assert r['graphs'] == 1
+    assert r['max_diff'] <= 1e-5 * max(1.0, r['peak']), r
