@@ -80,6 +80,9 @@ def parse():
                         'parameters in one launch when their last weight gradient is done '
                         '(beside the encoder backward), "buckets" = one launch per gradient '
                         'bucket')
+    p.add_argument('--graph', action='store_true',
+                   help='replay the step as ONE hipGraph launch (capture.CapturedTrainStep; '
+                        'single GPU, bit-identical results)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--cpu-samples', type=int, default=2)
@@ -111,8 +114,34 @@ class Harness:
             device) for i in range(a.pool)]
         self.reducer = None
         self.i = 0
+        self.captured = None
 
     def step(self):
+        if getattr(self.a, 'graph', False) and self.reducer is None:
+            return self.graph_step()
+        return self.eager_step()
+
+    def graph_step(self):
+        batch = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        if self.captured is None:
+            from dvs_of_training_framework_amd.capture import CapturedTrainStep
+            self.captured = CapturedTrainStep(self.model, self.losses, self.opt, [0.5, 1, 1],
+                                              self.device, batch)
+            loss = self.captured.first_loss
+        else:
+            loss, _ = self.captured(batch)
+        self.sched.step()
+        return loss
+
+    def suspend_graph(self):
+        """Per-launch instrumentation needs eager launches."""
+        if self.captured is not None:
+            self.captured.close()
+            self.captured = None
+        self.a.graph = False
+
+    def eager_step(self):
         from dvs_of_training_framework_amd.timer import FakeTimer
         from dvs_of_training_framework_amd.training import process_minibatch
         from dvs_of_training_framework_amd.loss import unit_backward
@@ -436,7 +465,10 @@ def main():
                     a.events or a.height * a.width,
                 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
         }
+    if rank == 0 and a.graph:
+        out['config']['launch'] = 'one hipGraph replay per step'
     if not a.no_roofline:
+        h.suspend_graph()       # per-launch HIP events need eager launches
         roof = measure_roofline(h, dt / a.steps * 1e3)   # every rank runs the same steps
         if rank == 0:
             out['roofline'] = roof
