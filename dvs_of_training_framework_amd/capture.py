@@ -79,7 +79,18 @@ class CapturedTrainStep:
         self.first_loss, self.first_terms = loss.detach().clone(), terms
         terms.host()
         torch.cuda.synchronize(dev)
-        # capture (p.grad stays the bucket views: same pointers as the tables)
+        # Eager objects the graph's kernels point at must outlive it whatever
+        # the caches that made them do later: index vectors of the layout,
+        # voxeliser workspace, gradient buckets, optimizer tables.
+        from . import voxel
+        self._keep = [dict(getattr(model, '_layout_cache', {})),
+                      list(voxel._WORKSPACES.values()),
+                      list(getattr(model.predictor, '_bucket_flat', [])),
+                      dict(optimizer._tables)]
+        # p.grad = None: the recorded backward WRITES the gradient buckets (and
+        # re-attaches them as .grad, same pointers as the optimizer's tables);
+        # with .grad set it would record the accumulate-into-.grad path
+        optimizer.zero_grad(set_to_none=True)
         optimizer.begin_capture(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -90,6 +101,7 @@ class CapturedTrainStep:
             optimizer.step()
         self.loss = loss.detach()
         self._terms = terms._terms      # _Terms: .packed is the [3,K] tensor
+        self._keep.append(optimizer._dyn)
         self.replays = 0
 
     @staticmethod

@@ -96,7 +96,9 @@ class Model(nn.Module):
                                            start + 1]),
                          start32=start.to(torch.int32),
                          stop32=(start + 1).to(torch.int32))
-                self._layout_cache = {key: c}
+                if len(self._layout_cache) >= 8:
+                    self._layout_cache.clear()
+                self._layout_cache[key] = c
             g = timestamps[c['gather']]
             self._fast = (c, g)
             return c['start'], c['stop'], g[:batch], g[batch:2 * batch]
