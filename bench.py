@@ -26,7 +26,8 @@ import sys
 import time
 from pathlib import Path
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # see dvs_of_training_framework_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see dvs_of_training_framework_amd/__init__.py
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
 
 import torch  # noqa: E402
 

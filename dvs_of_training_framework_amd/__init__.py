@@ -11,6 +11,13 @@ import os
 # (measured: 4.78 vs 4.36 ms/step with a process group).  Read when the HIP
 # runtime initialises, i.e. at the first torch.cuda use -- after this import.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# A captured training step (capture.py) replays its two backward branches on
+# the graph executor's own queues.  Measured on ROCm 7.2 (bench.py --graph,
+# batch 8): default queue count 4.17 ms/step (the branches spread over four
+# queues and the MFMA kernels slow each other down: 5.1 ms of kernel time per
+# step), 2 queues 3.52 ms, 1 queue 3.57 ms -- the eager two-stream schedule is
+# 3.25 ms.  Read by the HIP runtime at initialisation.
+os.environ.setdefault('DEBUG_HIP_FORCE_GRAPH_QUEUES', '2')
 
 
 def __getattr__(name):
