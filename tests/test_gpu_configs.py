@@ -198,9 +198,18 @@ def test_gradient_of_a_batch_is_the_mean_of_its_halves():
     l_a, g_a = grads(_split(b_np, B, 0, 4))
     l_b, g_b = grads(_split(b_np, B, 4, 8))
     assert abs(l_all - 0.5 * (l_a + l_b)) <= 1e-5 * abs(l_all)
+    # The identity is exact in real arithmetic.  In f32 the batch-8 and batch-4
+    # runs take different kernels (the residual layers reach the Winograd gate
+    # at 8 samples only; K splits of the weight gradients depend on the batch),
+    # whose ~1e-6 activation differences flip ReLU masks here and there:
+    # measured 5e-4 on the first encoder layer (the end of the backward
+    # chain), 1e-5..1e-4 elsewhere.  A wrong normaliser would show as O(1).
+    worst = {}
     for (name, _), g, a, b in zip(model.named_parameters(), g_all, g_a, g_b):
         mean = 0.5 * (a + b)
-        assert float((g - mean).norm()) <= 1e-4 * float(g.norm()) + 1e-12, name
+        worst[name] = float((g - mean).norm()) / (float(g.norm()) + 1e-12)
+    assert max(worst.values()) <= 2e-3, worst
+    assert sorted(worst.values())[len(worst) // 2] <= 3e-4, worst
 
 
 # ------------------------------------------------------------------- RCCL
