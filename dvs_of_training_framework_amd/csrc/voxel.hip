@@ -9,6 +9,7 @@
 // the five event columns, scatter with memory-side atomics into the grid that
 // was zero-filled on the same stream.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -104,8 +105,8 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t, const
 //     8-byte records {local pixel | lower bin | sign, fraction (exact f32)}.
 //     Buckets have a fixed capacity (2x the mean + slack); events that do not
 //     fit go to an overflow list (none for well-spread data).
-//   pass 2 (vox_tile_kernel): one workgroup per (sample, 64x16 tile): zero the
-//     [C][16][64] tile in LDS, ds_add_f32 the bucket's records, then the
+//   pass 2 (vox_tile_kernel): one workgroup per (sample, 1024-pixel tile): zero the
+//     [C][1024] tile in LDS, ds_add_f32 the bucket's records, then the
 //     overflow records that belong to this tile (the list is empty unless the
 //     events pile up in a few tiles), store the tile with coalesced rows.
 //     No global float atomics at all.
@@ -119,8 +120,10 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t, const
 // ===========================================================================
 namespace {
 
-constexpr int VTX = 64, VTY = 16;  // tile: 64 x 16 pixels (256-byte rows: full cache lines per store)
-constexpr int VPX = VTX * VTY;     // 1024 pixels: 10-bit local index
+// A tile is 1024 pixels (10-bit local index), 2^lx wide and 2^(10-lx) high;
+// lx is chosen per call (v2_plan): as wide as the frame allows, so that a
+// workgroup stores long contiguous runs of every output row it owns.
+constexpr int VPX = 1024;
 // events per thread in pass 1: 4 up to ~2 M events, 8 above (measured: 24.0 vs 26.3 us at
 // 0.5 M events, 111 vs 108 us at 4.2 M, 137 vs 121 us at 4 M events on 512 x 512 x 12)
 constexpr int64_t EPT8_FROM = 1 << 21;
@@ -138,7 +141,7 @@ struct VoxV2 {
     int enc;
     const float *t, *t0, *t1;
     int64_t n;
-    int B, C, H, W, TX, TY, ntile, cap;
+    int B, C, H, W, TX, TY, ntile, cap, lx;   // lx = log2(tile width)
     int32_t *cursor;      // [ntile] events reserved per tile (may exceed cap)
     int32_t *ovf_count;   // [1] overflow records
     int32_t *ovf_tiles;   // [1] tiles whose bucket overflowed
@@ -201,9 +204,9 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
                     c0 = min((int)floorf(tn), P.C - 1);
                     frac[k] = tn - (float)c0;
                     l = (int64_t)((((size_t)b * P.C + c0) * P.H + (size_t)yi) * P.W + (size_t)xi);
-                    const int ty = (int)yi / VTY, tx = (int)xi / VTX;
+                    const int ty = (int)yi >> (10 - P.lx), tx = (int)xi >> P.lx;
                     if (!zero) tile[k] = ((int)b * P.TY + ty) * P.TX + tx;
-                    key[k] = (unsigned)(((int)yi - ty * VTY) * VTX + ((int)xi - tx * VTX)) |
+                    key[k] = (unsigned)((((int)yi - (ty << (10 - P.lx))) << P.lx) + ((int)xi - (tx << P.lx))) |
                              ((unsigned)c0 << 10) | (neg ? 0x80000000u : 0u);
                 }
             }
@@ -302,11 +305,11 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
         }
     }
     __syncthreads();
-    // rows of 64 floats: 16 lanes x 16 bytes per row, full 128-byte lines
-    const int y0 = ty * VTY, x0 = tx * VTX;
+    // 16 bytes per lane along a tile row: full 128-byte lines, long runs for wide tiles
+    const int y0 = ty << (10 - P.lx), x0 = tx << P.lx;
     const bool vec = (P.W & 3) == 0 && ((uintptr_t)P.out & 15) == 0;
     for (int i = threadIdx.x * 4; i < nel; i += NT * 4) {
-        const int c = i / VPX, r = i - c * VPX, ly = r / VTX, lx = r - ly * VTX;
+        const int c = i / VPX, r = i - c * VPX, ly = r >> P.lx, lx = r - (ly << P.lx);
         const int y = y0 + ly, x = x0 + lx;
         if (y >= P.H || x >= P.W) continue;
         float *o = P.out + (((size_t)b * P.C + c) * P.H + y) * P.W + x;
@@ -331,8 +334,15 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
 
 bool v2_plan(int64_t n, int B, int C, int H, int W, VoxV2 &P)
 {
-    P.TX = (W + VTX - 1) / VTX;
-    P.TY = (H + VTY - 1) / VTY;
+    // tile width: the frame's width rounded up to a power of two, 64..1024
+    static const int lx_env = getenv("DVSOF_VOX_TILE_LOG2X") ? atoi(getenv("DVSOF_VOX_TILE_LOG2X")) : 0;
+    int lx = 6;
+    while (lx < 10 && (1 << lx) < W) ++lx;
+    if (lx_env >= 2 && lx_env <= 10) lx = lx_env;
+    P.lx = lx;
+    const int vtx = 1 << lx, vty = 1 << (10 - lx);
+    P.TX = (W + vtx - 1) / vtx;
+    P.TY = (H + vty - 1) / vty;
     const int64_t nt = (int64_t)B * P.TX * P.TY;
     if (nt > V2_MAX_TILES || (size_t)C * VPX * 4 > 150 * 1024 || C > 1023) return false;
     P.ntile = (int)nt;
