@@ -71,9 +71,10 @@ def parse():
                    help='events per sample (default H*W, SURVEY 8d)')
     p.add_argument('--pool', type=int, default=2,
                    help='distinct resident batches cycled through')
-    p.add_argument('--dtype', choices=('f32', 'bf16', 'bf16x3'), default='f32',
+    p.add_argument('--dtype', choices=('f32', 'bf16', 'bf16x3', 'bf16s'), default='f32',
                    help='conv matrix-core operand type (bf16: f32 storage and '
-                        'accumulation, operands rounded in registers)')
+                        'accumulation, operands rounded in registers; bf16s: bf16 twins of '
+                        'activations / gradients / prepared weights streamed through LDS)')
     p.add_argument('--fused-optimizer', nargs='?', const='coarse', default=None,
                    choices=('coarse', 'buckets'),
                    help='update parameters during the backward (optim.fuse_into_backward) '

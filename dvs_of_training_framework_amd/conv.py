@@ -16,7 +16,7 @@ NHWC, NCHW = 0, 1
 
 class Src(ctypes.Structure):
     """dvsof_src_t"""
-    _fields_ = [('p', _vp), ('C', _i), ('layout', _i)]
+    _fields_ = [('p', _vp), ('C', _i), ('layout', _i), ('p16', _vp)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -25,13 +25,14 @@ class ConvDesc(ctypes.Structure):
                 ('W', _i), ('upsample', _i), ('ksize', _i), ('stride', _i),
                 ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i),
                 ('scratch', _vp), ('scratch_bytes', _sz),
-                ('winograd_input', _vp)]
+                ('winograd_input', _vp), ('y16', _vp), ('w16', _vp),
+                ('gout16', _vp)]
 
 
 class GradDst(ctypes.Structure):
     """dvsof_grad_dst_t"""
     _fields_ = [('p', _vp), ('addend', _vp), ('addend2', _vp),
-                ('actsrc', _vp)]
+                ('actsrc', _vp), ('p16', _vp)]
 
 
 _P = ctypes.POINTER
@@ -48,7 +49,8 @@ _lib.register('dvsof_flow_head_fwd', _i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i,
 _lib.register('dvsof_flow_head_bwd_workspace_bytes', _sz, [_i, _i, _i, _i])
 _lib.register('dvsof_flow_head_bwd', _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp,
                                           _vp, _vp, _i, _i, _i, _i, _vp, _sz,
-                                          _vp])
+                                          _vp, _vp])
+_lib.register('dvsof_to_bf16', _i, [_vp, _vp, _sz, _vp])
 _lib.register('dvsof_act_bwd', _i, [_vp, _vp, _i, _vp, _sz, _vp])
 _lib.register('dvsof_conv2d_tile_id', _i, [_P(ConvDesc), _i])
 _lib.register('dvsof_conv2d_kernel_generation', _i, [_P(ConvDesc), _i])
@@ -59,18 +61,35 @@ _lib.register('dvsof_conv2d_scratch_bytes', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_winograd_tile', _i, [_P(ConvDesc), _i])
 
 
-MFMA_F32, MFMA_BF16, MFMA_BF16X3 = 0, 1, 2
+MFMA_F32, MFMA_BF16, MFMA_BF16X3, MFMA_BF16_TWINS = 0, 1, 2, 3
+
+
+def twin(t):
+    """Uninitialised bf16 twin buffer of an f32 tensor (mode 3: written by
+    the producing kernel next to the f32 tensor)."""
+    return torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+
+
+def to_bf16(src):
+    """bf16 twin of a prepared weight form (dvsof_to_bf16)."""
+    dst = torch.empty(src.numel(), dtype=torch.bfloat16, device=src.device)
+    _lib.check(_lib.lib().dvsof_to_bf16(src.data_ptr(), dst.data_ptr(),
+                                         src.numel(), _lib.stream()),
+               'dvsof_to_bf16')
+    return dst
 
 
 def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
               act=ACT_NONE, mfma=MFMA_F32):
-    """srcs: list of (tensor, C, layout)."""
+    """srcs: list of (tensor, C, layout[, bf16 twin])."""
     d = ConvDesc()
     d.nsrc = len(srcs)
-    for i, (t, C, layout) in enumerate(srcs):
+    for i, src in enumerate(srcs):
+        t, C, layout = src[:3]
         d.src[i].p = t.data_ptr()
         d.src[i].C = C
         d.src[i].layout = layout
+        d.src[i].p16 = _lib.ptr(src[3]) if len(src) > 3 else None
     d.B, d.H, d.W = B, H, W
     d.upsample = 1 if upsample else 0
     d.ksize, d.stride, d.pad = ksize, stride, pad
@@ -122,14 +141,18 @@ def _scratch(desc, device):
 
 
 def conv_fwd(desc, weight, bias, device, residual=None, want_z=False,
-             keep_input_transform=False):
-    """-> y [B,Ho,Wo,Cout] (NHWC buffer), z or None.
+             keep_input_transform=False, weight16=None):
+    """-> y [B,Ho,Wo,Cout] (NHWC buffer), z or None.  In mode 3
+    (MFMA_BF16_TWINS) ``desc._y16`` is y's bf16 twin afterwards.
     keep_input_transform: a Winograd layer's scratch (it starts with the
     transformed input) stays attached to ``desc`` for conv_wgrad."""
     ho, wo = out_size(desc)
     y = torch.empty(desc.B, ho, wo, desc.Cout, dtype=torch.float32,
                     device=device)
     z = torch.empty_like(y) if want_z else None
+    desc._y16 = twin(y) if desc.mfma == MFMA_BF16_TWINS else None
+    desc.y16 = _lib.ptr(desc._y16)
+    desc.w16 = _lib.ptr(weight16)
     ws = _scratch(desc, device)     # noqa: F841  (alive across the call)
     _lib.check(_lib.lib().dvsof_conv2d_fwd(
         ctypes.byref(desc), weight.data_ptr(), _lib.ptr(bias),
@@ -178,14 +201,18 @@ def flip_transpose(weight, Cout, ksize, Ctot):
     return wt
 
 
-def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE):
-    """dsts: list of dict(p=, addend=, addend2=, actsrc=) per source."""
+def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE, weight16=None,
+               gout16=None):
+    """dsts: list of dict(p=, addend=, addend2=, actsrc=[, p16=]) per source."""
     arr = (GradDst * len(dsts))()
     for i, d in enumerate(dsts):
         arr[i].p = d['p'].data_ptr()
         arr[i].addend = _lib.ptr(d.get('addend'))
         arr[i].addend2 = _lib.ptr(d.get('addend2'))
         arr[i].actsrc = _lib.ptr(d.get('actsrc'))
+        arr[i].p16 = _lib.ptr(d.get('p16'))
+    desc.w16 = _lib.ptr(weight16)
+    desc.gout16 = _lib.ptr(gout16)
     ws = _scratch(desc, gout.device)     # noqa: F841
     _lib.check(_lib.lib().dvsof_conv2d_dgrad(
         ctypes.byref(desc), weight_t.data_ptr(), gout.data_ptr(), arr,
@@ -212,14 +239,15 @@ def head_fwd(x, w, bias, B, H, W, C):
     return flow
 
 
-def head_bwd(x, w, gflow, gx_in, actsrc, act, gx, dw, dbias, B, H, W, C):
+def head_bwd(x, w, gflow, gx_in, actsrc, act, gx, dw, dbias, B, H, W, C,
+             gx16=None):
     nbytes = _lib.lib().dvsof_flow_head_bwd_workspace_bytes(B, H, W, C)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().dvsof_flow_head_bwd(
         x.data_ptr(), w.data_ptr(), gflow.data_ptr(), _lib.ptr(gx_in),
         _lib.ptr(actsrc), act, gx.data_ptr(), dw.data_ptr(),
-        _lib.ptr(dbias), B, H, W, C, ws.data_ptr(), nbytes, _lib.stream()),
-        'dvsof_flow_head_bwd')
+        _lib.ptr(dbias), B, H, W, C, ws.data_ptr(), nbytes, _lib.ptr(gx16),
+        _lib.stream()), 'dvsof_flow_head_bwd')
 
 
 def act_bwd(dy, actsrc, act, out=None):

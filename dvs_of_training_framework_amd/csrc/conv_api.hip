@@ -27,10 +27,11 @@ int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *gout, float
 
 namespace {
 
-GSrc make_src(const float *p, int C, int layout, int H, int W)
+GSrc make_src(const float *p, int C, int layout, int H, int W, const void *p16 = nullptr)
 {
     GSrc s;
     s.p = p;
+    s.p16 = layout == DVSOF_NHWC ? (const unsigned short *)p16 : nullptr;
     s.C = C;
     if (layout == DVSOF_NCHW) {
         s.sb = (long long)C * H * W;
@@ -243,7 +244,7 @@ template <int LPP>
 __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ gflow,
     const float *gx_in, const float *__restrict__ actsrc, int act, float *gx,
-    float *__restrict__ part, int B, int HW)
+    float *__restrict__ part, int B, int HW, unsigned short *__restrict__ gx16)
 {
     constexpr int C = LPP * 4, PPW = 64 / LPP;
     __shared__ float red[4][2 * C + 2];
@@ -275,6 +276,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
                 for (int i = 0; i < 4; ++i) g[i] *= act_bwd(sv[i], act);
             }
             *(f32x4u *)(gx + o) = g;
+            if (gx16) {     // bf16 twin for the data gradient that reads it next
+                typedef unsigned short u16x4 __attribute__((ext_vector_type(4), aligned(2)));
+                const u16x4 h = {bf16_bits(g[0]), bf16_bits(g[1]), bf16_bits(g[2]), bf16_bits(g[3])};
+                *(u16x4 *)(gx16 + o) = h;
+            }
         }
     }
     // lanes with equal `sub` hold partial sums of the same channels
@@ -338,6 +344,24 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *dy,
     }
 }
 
+// bf16 twins of prepared weights: 8 elements per thread and iteration
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ src,
+                                                      unsigned short *__restrict__ dst, size_t n)
+{
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8), aligned(4)));
+    const size_t stride = (size_t)gridDim.x * 256 * 8;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 7 < n) {
+            const f32x4 a = *(const f32x4u *)(src + i), b = *(const f32x4u *)(src + i + 4);
+            const u16x8 h = {bf16_bits(a[0]), bf16_bits(a[1]), bf16_bits(a[2]), bf16_bits(a[3]),
+                             bf16_bits(b[0]), bf16_bits(b[1]), bf16_bits(b[2]), bf16_bits(b[3])};
+            *(u16x8 *)(dst + i) = h;
+        } else {
+            for (size_t j = i; j < n; ++j) dst[j] = bf16_bits(src[j]);
+        }
+    }
+}
+
 // workgroups of the head backward = partial rows of its weight-gradient reduce
 int head_blocks(long long total, int lpp)
 {
@@ -349,7 +373,7 @@ int head_blocks(long long total, int lpp)
 
 void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParams &P)
 {
-    P.mfma_bf16 = (d->mfma == 1 || d->mfma == 2) ? d->mfma : 0;
+    P.mfma_bf16 = d->mfma == 3 ? 1 : (d->mfma == 1 || d->mfma == 2) ? d->mfma : 0;   // twins: f32 tensors, rounded operands
     const int up = d->upsample ? 2 : 1;
     P.nsrc = d->nsrc;
     for (int i = 0; i < d->nsrc; ++i)
@@ -440,10 +464,12 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     GConvParams P = {};
     P.nsrc = d->nsrc;
     for (int i = 0; i < d->nsrc; ++i)
-        P.src[i] = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+        P.src[i] = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W, d->src[i].p16);
     P.ndst = 1;
-    P.dst[0] = {y, residual, nullptr, nullptr, (long long)Ho * Wo * d->Cout, Wo * d->Cout, d->Cout, 1, d->Cout, 0, 0};
+    P.dst[0] = {y, residual, nullptr, nullptr, (long long)Ho * Wo * d->Cout, Wo * d->Cout, d->Cout, 1, d->Cout, 0, 0,
+                d->mfma == 3 ? (unsigned short *)d->y16 : nullptr};
     P.W = weight;
+    P.W16 = d->mfma == 3 ? (const unsigned short *)d->w16 : nullptr;
     P.bias = bias;
     P.zout = z;
     P.B = d->B;
@@ -461,7 +487,7 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     P.M = d->B * Ho * Wo;
     P.quad = 0;
     P.act = d->act;
-    P.mfma_bf16 = (d->mfma == 1 || d->mfma == 2) ? d->mfma : 0;
+    P.mfma_bf16 = (d->mfma >= 1 && d->mfma <= 3) ? d->mfma : 0;
     P.bwd_act = ACT_NONE;
     P.nph = 1;
     P.ph_pad = 0;
@@ -494,14 +520,16 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
     if (!desc_ok(d, Ctot, Ho, Wo) || !weight_t || !gout || !dst) return DVSOF_EINVAL;
     GConvParams P = {};
     P.nsrc = 1;
-    P.src[0] = make_src(gout, d->Cout, DVSOF_NHWC, Ho, Wo);
+    P.src[0] = make_src(gout, d->Cout, DVSOF_NHWC, Ho, Wo, d->mfma == 3 ? d->gout16 : nullptr);
     P.ndst = d->nsrc;
     for (int i = 0; i < d->nsrc; ++i) {
         if (!dst[i].p) return DVSOF_EINVAL;
         const GSrc g = make_src(nullptr, d->src[i].C, d->src[i].layout, d->H, d->W);
-        P.dst[i] = {dst[i].p, dst[i].addend, dst[i].addend2, dst[i].actsrc, g.sb, g.sy, g.sx, g.sc, g.C, 0, 0};
+        P.dst[i] = {dst[i].p, dst[i].addend, dst[i].addend2, dst[i].actsrc, g.sb, g.sy, g.sx, g.sc, g.C, 0, 0,
+                    (d->mfma == 3 && d->src[i].layout == DVSOF_NHWC) ? (unsigned short *)dst[i].p16 : nullptr};
     }
     P.W = weight_t;
+    P.W16 = d->mfma == 3 ? (const unsigned short *)d->w16 : nullptr;
     P.bias = nullptr;
     P.zout = nullptr;
     P.B = d->B;
@@ -511,7 +539,7 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
     P.N = Ctot;
     P.Cin_tot = d->Cout;
     P.act = ACT_NONE;
-    P.mfma_bf16 = (d->mfma == 1 || d->mfma == 2) ? d->mfma : 0;
+    P.mfma_bf16 = (d->mfma >= 1 && d->mfma <= 3) ? d->mfma : 0;
     P.bwd_act = bwd_act;
     P.nph = 1;
     P.ph_pad = 0;
@@ -792,7 +820,7 @@ size_t dvsof_flow_head_bwd_workspace_bytes(int B, int H, int W, int C)
 
 int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow, const float *gx_in,
                         const float *actsrc, int act, float *gx, float *dw, float *dbias, int B,
-                        int H, int W, int C, void *ws, size_t ws_bytes, void *stream)
+                        int H, int W, int C, void *ws, size_t ws_bytes, void *gx16, void *stream)
 {
     if (!x || !w || !gflow || !gx || !dw || !ws || B < 1 || H < 1 || W < 1 || !head_c_ok(C))
         return DVSOF_EINVAL;
@@ -800,10 +828,23 @@ int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow, cons
     hipStream_t st = as_stream(stream);
     const int nb = head_blocks((long long)B * H * W, C / 4);
     float *part = (float *)ws;
-    HEAD_DISPATCH(head_bwd_kernel, nb, x, w, gflow, gx_in, actsrc, act, gx, part, B, H * W);
+    HEAD_DISPATCH(head_bwd_kernel, nb, x, w, gflow, gx_in, actsrc, act, gx, part, B, H * W,
+                  (unsigned short *)gx16);
     DVSOF_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((2 * C + 2 + 3) / 4), dim3(256), 0, st,
                        (const float *)part, nb, C, dw, dbias);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_to_bf16(const float *src, void *dst, size_t n, void *stream)
+{
+    if (!src || !dst) return DVSOF_EINVAL;
+    if (n == 0) return DVSOF_OK;
+    size_t nb = (n + 2047) / 2048;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), src,
+                       (unsigned short *)dst, n);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

@@ -26,6 +26,7 @@ struct GSrc {
     int sy, sx, sc;   // row / pixel / channel strides (elements)
     int C;            // channels
     int flat;         // 1: scalar path, K flattened over (tap, channel)
+    const unsigned short *p16;   // bf16 twin (same shape / strides in elements) or null
 };
 
 // One destination channel range of the output.
@@ -38,12 +39,14 @@ struct GDst {
     int sy, sx, sc;
     int C;
     int ph_y, ph_x;       // element offsets of output phase (py, px)
+    unsigned short *p16;  // optional bf16 twin of p, written with the same offsets
 };
 
 struct GConvParams {
     GSrc src[3];
     GDst dst[3];
     const float *W;     // [N][taps][Cin_tot], K contiguous
+    const unsigned short *W16;   // bf16 twin of W (mfma_bf16 == 3)
     const float *bias;  // [N] or null
     float *zout;        // optional pre-activation copy, indexed like dst[0]
     int nsrc, ndst;
@@ -63,6 +66,8 @@ struct GConvParams {
     int mfma_bf16;      // 1: operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16
                         // (f32 accumulate; every tensor stays f32 in memory);
                         // 2: operands split hi + lo, three bf16 products (~2^-16 relative)
+                        // 3: bf16 twins: the vector members' p16 and W16 stream through LDS as bf16
+                        //    (gconv2 only; other kernels treat it as 1)
     int ph_exact;       // phased stride-2 dgrad: phase (py,px) only has (1+py) x (1+px) non-zero
                         // taps; a kernel MAY skip the others (they multiply zero weights)
     int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step, 4 = loads from one L2-resident KiB,
@@ -106,6 +111,13 @@ __device__ __forceinline__ float mish_t(float x, float &n)
 {
     n = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.4426950408889634f);
     return n * (n + 2.f);
+}
+
+// f32 -> bf16 bits, round to nearest even
+__device__ __forceinline__ unsigned short bf16_bits(float v)
+{
+    const __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, h);
 }
 
 __device__ __forceinline__ float act_fwd(float v, int act)
@@ -228,6 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
         // destination (channel range) of this lane's column
         int dsel = 0, off = 0, run = 0;
         float *dp = P.dst[0].p;
+        unsigned short *dp16 = P.dst[0].p16;
         const float *a1 = P.dst[0].addend, *a2 = P.dst[0].addend2, *as = P.dst[0].actsrc;
         int sc = P.dst[0].sc;
         for (int d = 1; d < P.ndst; ++d) {
@@ -236,6 +249,7 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
                 dsel = d;
                 off = run;
                 dp = P.dst[d].p;
+                dp16 = P.dst[d].p16;
                 a1 = P.dst[d].addend;
                 a2 = P.dst[d].addend2;
                 as = P.dst[d].actsrc;
@@ -285,8 +299,15 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
                         if (o[reg] >= 0) P.zout[o[reg]] = v[reg];
                 }
 #pragma unroll
+                for (int reg = 0; reg < 16; ++reg) v[reg] = act_fwd(v[reg], P.act);
+#pragma unroll
                 for (int reg = 0; reg < 16; ++reg)
-                    if (o[reg] >= 0) dp[o[reg]] = act_fwd(v[reg], P.act);
+                    if (o[reg] >= 0) dp[o[reg]] = v[reg];
+                if (dp16) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (o[reg] >= 0) dp16[o[reg]] = bf16_bits(v[reg]);
+                }
             } else {   // quad rows: the lane's 4 consecutive registers are one low-res pixel
                 long long o[4];
                 float v[4];
@@ -310,6 +331,7 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
                     if (a2) v[g] += t2[g];
                     if (as) v[g] *= act_bwd(t3[g], P.bwd_act);
                     if (o[g] >= 0) dp[o[g]] = v[g];
+                    if (dp16 && o[g] >= 0) dp16[o[g]] = bf16_bits(v[g]);
                 }
             }
         }

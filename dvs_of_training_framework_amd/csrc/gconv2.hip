@@ -84,6 +84,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
     const int nvec = P.ph_exact ? nvec_all / (P.ks * P.ks) * (kh * kw) : nvec_all;
     const float *Wp = P.W + (size_t)ph * P.w_phase_stride;
+    const unsigned short *Wp16 = P.W16 ? P.W16 + (size_t)ph * P.w_phase_stride : nullptr;
     const size_t wrow = (size_t)taps * P.Cin_tot;
 
     for (int r = tid; r < BM; r += NT) {
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     // wave tiles of ONE 32x32 block: a second accumulator for the odd k-quads
     // halves the length of the dependent MFMA chain
     constexpr bool DUAL = (TM * TN == 1) && (BF16 == 0);
+    constexpr int EB = BF16 == 3 ? 2 : 4;      // bytes per operand element in HBM and LDS
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -162,7 +164,20 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     };
     auto mfma_slice = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if constexpr (BF16 != 0) {
+        if constexpr (BF16 == 3) {
+            // bf16 twins: a 16-byte k-quad IS eight bf16 values of K -- one
+            // 32x32x16 MFMA per quad, nothing to convert.  A and B read the
+            // same quad index, i.e. the same eight k.
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, fa[buf][j][tm]),
+                            __builtin_bit_cast(bf16x8, fb[buf][j][tn]), acc[tm][tn], 0, 0, 0);
+        } else if constexpr (BF16 != 0) {
             // the lane's two k-quads (8 values) of a 16-wide slice feed ONE
             // 32x32x16 bf16 MFMA; A and B use the same k -> (lane, position) map.
             // BF16 == 2: split operands a = hi + lo (both bf16) and three products
@@ -247,15 +262,28 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                     v = S.p[(size_t)rowB[r] * S.sb + (size_t)ys * S.sy + (size_t)xs * S.sx +
                             (size_t)c * S.sc];
                 }
+                if constexpr (BF16 == 3) {   // k = kk lives in quad kk>>3 as bf16; quads 2, 3 are zero
+                    unsigned char *row = smem + r * 64;
+                    *(unsigned short *)(row + ((((kk >> 3)) ^ ((r >> 2) & 3)) << 4) + (kk & 7) * 2) = bf16_bits(v);
+                    *(unsigned short *)(row + ((((kk >> 3) + 2) ^ ((r >> 2) & 3)) << 4) + (kk & 7) * 2) = 0;
+                } else
                 *(float *)(smem + r * 64 + ((((kk >> 2) ^ ((r >> 2) & 3))) << 4) + (kk & 3) * 4) = v;
             }
 #pragma unroll
             for (int i = 0; i < BN / 16; ++i) {
                 const int r = (tid >> 4) + 16 * i, n = n0 + r;
+                if constexpr (BF16 == 3) {
+                    const unsigned short v16 = (fok && n < P.N)
+                        ? Wp16[(size_t)n * wrow + (size_t)tap * P.Cin_tot + coff + c] : (unsigned short)0;
+                    unsigned char *row = smem + PA * 1024 + r * 64;
+                    *(unsigned short *)(row + ((((kk >> 3)) ^ ((r >> 2) & 3)) << 4) + (kk & 7) * 2) = v16;
+                    *(unsigned short *)(row + ((((kk >> 3) + 2) ^ ((r >> 2) & 3)) << 4) + (kk & 7) * 2) = 0;
+                } else {
                 const float v = (fok && n < P.N)
                                     ? Wp[(size_t)n * wrow + (size_t)tap * P.Cin_tot + coff + c] : 0.f;
                 *(float *)(smem + PA * 1024 + r * 64 + ((((kk >> 2) ^ ((r >> 2) & 3))) << 4) +
                            (kk & 3) * 4) = v;
+                }
             }
             __syncthreads();
             compute1(smem);
@@ -300,11 +328,11 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             } else {
                 const int n = n0 + r;
                 sb_[i] = sy_[i] = sx_[i] = 0;
-                voff[i] = (r < BN && n < P.N) ? (unsigned)(n * wrow * 4) + slot_kq4[i] : OOB;
+                voff[i] = (r < BN && n < P.N) ? (unsigned)(n * wrow * EB) + slot_kq4[i] : OOB;
             }
         }
-        const __amdgpu_buffer_rsrc_t wres =
-            __builtin_amdgcn_make_buffer_rsrc((void *)Wp, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+            BF16 == 3 ? (void *)Wp16 : (void *)Wp, 0, 0x7fffffff, 0x00020000);
 
         // K-slice iterator, all in SGPRs: member s, tap (ky,kx), chunk c0
         int it_s = 0, it_coff = 0;
@@ -312,14 +340,20 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             it_coff += P.src[it_s].C;
             ++it_s;
         }
+        // it_c0 / it_C count 4-byte units of a pixel's channel run (f32: channels;
+        // bf16 twins: channel pairs); it_coff counts channels of the weight row
         int it_ky = 0, it_kx = 0, it_c0 = 0;
-        int it_C = P.src[it_s].C;
+        int it_C = P.src[it_s].C * EB / 4;
         bool new_tap = true;
         long long a_sb = P.src[it_s].sb;
         int a_sy = P.src[it_s].sy, a_sx = P.src[it_s].sx;
         const size_t a_ph = (size_t)ph * P.src_ph_stride;
+        auto src_base = [&](int s_) -> void * {
+            if constexpr (BF16 == 3) return (void *)(P.src[s_].p16 + a_ph);
+            else return (void *)(P.src[s_].p + a_ph);
+        };
         __amdgpu_buffer_rsrc_t ares =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(P.src[it_s].p + a_ph), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(src_base(it_s), 0, 0x7fffffff, 0x00020000);
 
         auto issue_impl = [&](auto probec, int stage_idx) {
             constexpr bool PROBE = decltype(probec)::value;   // timing probes compiled in?
@@ -333,7 +367,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                         if (P.up == UP_ZERO) ok &= ((Y | X) & 1) == 0;
                         const int ys = P.up ? Y >> 1 : Y, xs = P.up ? X >> 1 : X;
                         const unsigned o = (unsigned)(((long long)sb_[i] * a_sb + (long long)ys * a_sy +
-                                                       (long long)xs * a_sx) * 4) + slot_kq4[i];
+                                                       (long long)xs * a_sx) * EB) + slot_kq4[i];
                         voff[i] = ok ? o : OOB;
                     }
                 }
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                 // pattern, cache-resident footprint)
                 const int a_soff = (PROBE && (P.dbg & 128)) ? 0 : __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
                 const int b_soff = (PROBE && (P.dbg & 128)) ? 0 : __builtin_amdgcn_readfirstlane(
-                    ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff + it_c0 + sub * BK) * 4);
+                    ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff) * EB + (it_c0 + sub * BK) * 4);
                 unsigned char *st = smem + stage_idx * STAGE + sub * SUB;
 #pragma unroll
                 for (int i = 0; i < NSLOT; ++i) {
@@ -372,19 +406,19 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                     it_kx = 0;
                     if (++it_ky == kh) {
                         it_ky = 0;
-                        it_coff += it_C;
+                        it_coff += P.src[it_s].C;
                         ++it_s;
                         while (it_s < P.nsrc && P.src[it_s].flat) {
                             it_coff += P.src[it_s].C;
                             ++it_s;
                         }
                         if (it_s < P.nsrc) {
-                            it_C = P.src[it_s].C;
+                            it_C = P.src[it_s].C * EB / 4;
                             a_sb = P.src[it_s].sb;
                             a_sy = P.src[it_s].sy;
                             a_sx = P.src[it_s].sx;
-                            ares = __builtin_amdgcn_make_buffer_rsrc((void *)(P.src[it_s].p + a_ph), 0,
-                                                                     0x7fffffff, 0x00020000);
+                            ares = __builtin_amdgcn_make_buffer_rsrc(src_base(it_s), 0, 0x7fffffff,
+                                                                     0x00020000);
                         }
                     }
                 }
@@ -511,6 +545,7 @@ int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 template <int WROWS, int WCOLS, int TM, int TN, int KSUB, int NS, int KSPLIT = 1>
 int launch2(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
+    if (P.mfma_bf16 == 3) return launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, 3>(P, nflat, nvec, st);
     if (P.mfma_bf16 == 2) return launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, 2>(P, nflat, nvec, st);
     if (P.mfma_bf16 == 1) return launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, 1>(P, nflat, nvec, st);
     return launch2x<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, 0>(P, nflat, nvec, st);
@@ -539,12 +574,21 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
     static const int dbg = getenv("DVSOF_GCONV_DBG") ? atoi(getenv("DVSOF_GCONV_DBG")) : 0;
     P.dbg = dbg;
     const int taps = P.ks * P.ks;
+    // bf16 twins: every vector member needs its twin, the weights theirs, and a
+    // pixel's channel run must be whole 64-byte K slices (32 bf16); else mode 1
+    if (P.mfma_bf16 == 3) {
+        bool ok = P.W16 != nullptr && P.src_ph_stride == 0 && (P.Cin_tot & 1) == 0;
+        for (int s = 0; s < P.nsrc; ++s)
+            if (!P.src[s].flat && (!P.src[s].p16 || (P.src[s].C % (2 * BK)))) ok = false;
+        if (!ok) P.mfma_bf16 = 1;
+    }
+    const int unit = P.mfma_bf16 == 3 ? 2 : 1;     // channels per 4-byte unit of a K slice
     // K depth per barrier: 32 when every vector member allows it (small tiles
     // run 1-2 waves per SIMD, where the per-slice sync cost is exposed)
     static const bool k16 = getenv("DVSOF_GCONV_K16") != nullptr;
     bool k32 = !k16 && (tile == 2 || tile == 3);
     for (int s = 0; s < P.nsrc; ++s)
-        if (!P.src[s].flat && (P.src[s].C % (2 * BK))) k32 = false;
+        if (!P.src[s].flat && ((P.src[s].C / unit) % (2 * BK))) k32 = false;
     {   // larger stages cost occupancy: only when the grid is <= 2 workgroups per CU anyway
         const long long bm = 128 >> (tile == 3), bn = 64;
         const long long blocks = ((P.M + bm - 1) / bm) * ((P.N + bn - 1) / bn) * P.nph;
@@ -559,13 +603,13 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
         const long long blocks = ((P.M + 63) / 64) * ((P.N + 63) / 64) * P.nph;
         k64 = blocks <= 256;
         for (int s = 0; s < P.nsrc; ++s)
-            if (P.src[s].flat || (P.src[s].C % (4 * BK))) k64 = false;
+            if (P.src[s].flat || ((P.src[s].C / unit) % (4 * BK))) k64 = false;
         if (k64) ksub = 4;
     }
     int nflat = 0, nvec = 0;
     for (int s = 0; s < P.nsrc; ++s) {
         if (P.src[s].flat) nflat += (taps * P.src[s].C + BK - 1) / BK;
-        else nvec += taps * (P.src[s].C / (BK * ksub));
+        else nvec += taps * (P.src[s].C / unit / (BK * ksub));
     }
     if (dbg & 2) nvec = nvec > 1 ? 1 : nvec;
     if (nflat > 0 || getenv("DVSOF_NO_PH_EXACT")) P.ph_exact = 0;

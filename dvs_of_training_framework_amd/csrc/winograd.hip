@@ -481,7 +481,7 @@ bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int B, int H, 
     static const bool off = getenv("DVSOF_NO_WINOGRAD") != nullptr;
     if (off) return false;
     if (nsrc != 1 || !layout_nhwc || upsample || ksize != 3 || stride != 1 || pad != 1) return false;
-    if (mfma == 1) return false;   // bf16-rounded operands: the transforms amplify the rounding
+    if (mfma == 1 || mfma == 3) return false;   // bf16-rounded operands: the transforms amplify the rounding
     if ((C % 64) || (N % 64) || C < 256 || N < 256) return false;
     return wino_tile(B, H, W, mfma == 2 ? 2 : 0) != 0;
 }

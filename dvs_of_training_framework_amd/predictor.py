@@ -85,6 +85,7 @@ class _PredictorFn(torch.autograd.Function):
         act = module.act
         B, Cin, H, W = x0.shape
         mish = act == C.ACT_MISH
+        twins = module.mfma == C.MFMA_BF16_TWINS
         p = list(params)
         enc = [(p[2 * i], p[2 * i + 1]) for i in range(4)]
         o = 8
@@ -129,13 +130,15 @@ class _PredictorFn(torch.autograd.Function):
                                      module.mfma)
                     w_f, _ = C.prepare(d_, _phys(wgt_), False)
                     if w_f is not wgt_:
-                        pre[li] = w_f
+                        pre[li] = (w_f, C.to_bf16(w_f) if twins else None)
             pre_ready = torch.cuda.Event()
             pre_ready.record(side)
         waited = [False]
 
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
+            """-> (y, y16): the layer's output and, in the bf16-twins mode,
+            its bf16 copy (written by the same kernel)."""
             d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act,
                             module.mfma)
             # prepared weights: sub-pixel phase kernels for the decoder,
@@ -143,9 +146,10 @@ class _PredictorFn(torch.autograd.Function):
             # data-gradient form, made once per step
             first = len(L) == 0       # voxel input needs no data gradient
             need_dg = want_grad and not first
+            w_fwd16 = w_dg16 = None
             if side is not None and need_dg:
                 if len(L) in pre:             # made on the second stream
-                    w_fwd = pre[len(L)]
+                    w_fwd, w_fwd16 = pre[len(L)]
                     if not waited[0]:
                         main.wait_event(pre_ready)
                         waited[0] = True
@@ -158,33 +162,46 @@ class _PredictorFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     _, w_dg = C.prepare(d, _phys(wgt), True,
                                         phase_weights=w_fwd)
+                    if twins:
+                        w_dg16 = C.to_bf16(w_dg)
             else:
                 w_fwd, w_dg = C.prepare(d, _phys(wgt), need_dg)
+                if twins and w_dg is not None:
+                    w_dg16 = C.to_bf16(w_dg)
+            if twins and w_fwd16 is None:
+                w_fwd16 = C.to_bf16(w_fwd)
             y, z = C.conv_fwd(d, w_fwd, bias, dev, residual, mish,
-                              keep_input_transform=want_grad)
-            L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg))
-            return y
+                              keep_input_transform=want_grad,
+                              weight16=w_fwd16)
+            L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg,
+                          w_dg16=w_dg16))
+            return y, d._y16
 
-        # encoder
+        # encoder (activations travel as (f32 tensor, bf16 twin or None))
         e, h, w = [], H, W
-        cur, ccur, lay = x0, Cin, C.NCHW
+        cur, ccur, lay = (x0, None), Cin, C.NCHW
         for i in range(4):
-            cur = run([(cur, ccur, lay)], h, w, ENC_CH[i], *enc[i], stride=2)
+            cur = run([(cur[0], ccur, lay, cur[1])], h, w, ENC_CH[i], *enc[i],
+                      stride=2)
             h, w, ccur, lay = h // 2, w // 2, ENC_CH[i], C.NHWC
             e.append(cur)
         # residual blocks
         r = e[3]
         for i in range(NUM_RES):
-            t = run([(r, 512, C.NHWC)], h, w, 512, res[i][0], res[i][1])
-            r = run([(t, 512, C.NHWC)], h, w, 512, res[i][2], res[i][3],
-                    residual=r)
+            t = run([(t_[0], 512, C.NHWC, t_[1]) for t_ in (r,)], h, w, 512,
+                    res[i][0], res[i][1])
+            r = run([(t[0], 512, C.NHWC, t[1])], h, w, 512, res[i][2],
+                    res[i][3], residual=r[0])
         # decoder
-        flows, x, cx, f = [], r, 512, None
+        flows, xx, cx, f = [], r, 512, None
         for i in range(4):
-            srcs = [(x, cx, C.NHWC), (e[3 - i], ENC_CH[3 - i], C.NHWC)]
+            sk = e[3 - i]
+            srcs = [(xx[0], cx, C.NHWC, xx[1]),
+                    (sk[0], ENC_CH[3 - i], C.NHWC, sk[1])]
             if f is not None:
                 srcs.append((f, 2, C.NCHW))
-            x = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True)
+            xx = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True)
+            x = xx[0]
             h, w, cx = 2 * h, 2 * w, DEC_CH[i]
             f = C.head_fwd(x, dec[i][2], dec[i][3], B, h, w, cx)
             flows.append(f)
@@ -215,6 +232,11 @@ class _PredictorFn(torch.autograd.Function):
 
         def new(t):
             return torch.empty_like(t)
+
+        twins = ctx.module.mfma == C.MFMA_BF16_TWINS
+
+        def tw(t):          # bf16 twin of a gradient a later data gradient reads
+            return C.twin(t) if twins else None
 
         enc_l, res_l, dec_l = L[0:4], L[4:4 + 2 * NUM_RES], L[4 + 2 * NUM_RES:]
         po_res, po_dec = 8, 8 + 4 * NUM_RES
@@ -247,55 +269,62 @@ class _PredictorFn(torch.autograd.Function):
         g_x = None          # gradient w.r.t. dec[i].y from the finer stage
         g_f = gflows[3]     # total gradient of the flow of this stage
         g_skip = [None] * 4  # gradient into e[k] from the decoder
-        g_r = None
+        g_r = g_r16 = None
         for i in (3, 2, 1, 0):
             lay = dec_l[i]
             d = lay['desc']
             h, w = C.out_size(d)
             y = lay['y']
-            gz = new(y)
+            gz, gz16 = new(y), tw(y)
             pw, pb, pfw, pfb = (po_dec + 4 * i + j for j in range(4))
             C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
-                       grads[pfw], grads[pfb], B, h, w, d.Cout)
+                       grads[pfw], grads[pfb], B, h, w, d.Cout, gx16=gz16)
             wgrad(d, gz, grads[pw], grads[pb], ('dec', i))
             srcs = lay['srcs']
             g_in = new(srcs[0][0])
             g_e = new(srcs[1][0])
             dsts = [dict(p=g_in), dict(p=g_e)]
             if i == 0:
-                # x = r (last residual output): single consumer -> its dz
+                # x = r (last residual output): single consumer -> its dz,
+                # which the residual chain's data gradients read next
                 dsts[0]['actsrc'] = asrc(res_l[-1])
+                g_r16 = dsts[0]['p16'] = tw(g_in)
             if len(srcs) == 3:
                 g_fprev = new(srcs[2][0])
                 dsts.append(dict(p=g_fprev, addend=gflows[i - 1]))
-            C.conv_dgrad(d, wt(lay), gz, dsts, act)
+            C.conv_dgrad(d, wt(lay), gz, dsts, act, weight16=lay['w_dg16'],
+                         gout16=gz16)
+            keep.append(gz16)
             g_skip[3 - i] = g_e
             if i > 0:
                 g_x, g_f = g_in, g_fprev
             else:
                 g_r = g_in
         # ---- residual blocks (g_r is already d/d pre-activation)
-        gs = g_r
+        gs, gs16 = g_r, g_r16
         for i in reversed(range(NUM_RES)):
             l1, l2 = res_l[2 * i], res_l[2 * i + 1]
             pw1, pb1, pw2, pb2 = (po_res + 4 * i + j for j in range(4))
             wgrad(l2['desc'], gs, grads[pw2], grads[pb2], ('res', i, 2))
-            g_t = new(l1['y'])
+            g_t, g_t16 = new(l1['y']), tw(l1['y'])
             C.conv_dgrad(l2['desc'], wt(l2), gs,
-                         [dict(p=g_t, actsrc=asrc(l1))], act)
+                         [dict(p=g_t, actsrc=asrc(l1), p16=g_t16)], act,
+                         weight16=l2['w_dg16'], gout16=gs16)
             wgrad(l1['desc'], g_t, grads[pw1], grads[pb1], ('res', i, 1))
             below = res_l[2 * i - 1] if i > 0 else enc_l[3]
-            g_prev = new(below['y'])
-            dst = dict(p=g_prev, addend=gs, actsrc=asrc(below))
+            g_prev, g_prev16 = new(below['y']), tw(below['y'])
+            dst = dict(p=g_prev, addend=gs, actsrc=asrc(below), p16=g_prev16)
             if i == 0:
                 dst['addend2'] = g_skip[3]      # dec.0's skip into e4
-            C.conv_dgrad(l1['desc'], wt(l1), g_t, [dst], act)
-            gs = g_prev
+            C.conv_dgrad(l1['desc'], wt(l1), g_t, [dst], act,
+                         weight16=l1['w_dg16'], gout16=g_t16)
+            keep.extend((gs16, g_t16))
+            gs, gs16 = g_prev, g_prev16
         # ---- encoder.  Its weight gradients are issued on the MAIN stream after
         # the last data gradient: by then the second stream still holds the
         # residual blocks' weight gradients, and the main stream would only
         # wait for it -- this way both streams drain the tail together.
-        gz = gs
+        gz, gz16 = gs, gs16
         deferred = []
         n_side = int(os.environ.get('DVSOF_ENC_SIDE_FROM', '2'))
         for i in (3, 2, 1, 0):
@@ -308,11 +337,13 @@ class _PredictorFn(torch.autograd.Function):
             if i == 0:
                 break
             below = enc_l[i - 1]
-            g_prev = new(below['y'])
+            g_prev, g_prev16 = new(below['y']), tw(below['y'])
             C.conv_dgrad(lay['desc'], wt(lay), gz,
                          [dict(p=g_prev, addend=g_skip[i - 1],
-                               actsrc=asrc(below))], act)
-            gz = g_prev
+                               actsrc=asrc(below), p16=g_prev16)], act,
+                         weight16=lay['w_dg16'], gout16=gz16)
+            keep.append(gz16)
+            gz, gz16 = g_prev, g_prev16
         for desc, g, gw, gb, unit in deferred:
             if side is None:
                 wgrad(desc, g, gw, gb, unit)
@@ -337,7 +368,13 @@ class Predictor(nn.Module):
         # 'bf16x3': operands split into bf16 hi + lo, three products (error
         # ~2^-16 per product instead of 2^-24): f32-like accuracy at the bf16
         # matrix rate.
-        modes = {'f32': C.MFMA_F32, 'bf16': C.MFMA_BF16, 'bf16x3': C.MFMA_BF16X3}
+        # 'bf16s': bf16 operands as in 'bf16', but the forward / data-gradient
+        # kernels stream bf16 TWINS of the activations, gradients and prepared
+        # weights through LDS (half the LDS-DMA bytes 'bf16' is bound by);
+        # every f32 tensor is still written (weight gradients, heads and loss
+        # read those), master weights / optimizer state stay f32.
+        modes = {'f32': C.MFMA_F32, 'bf16': C.MFMA_BF16, 'bf16x3': C.MFMA_BF16X3,
+                 'bf16s': C.MFMA_BF16_TWINS}
         assert compute_dtype in modes, compute_dtype
         self.compute_dtype = compute_dtype
         self.mfma = modes[compute_dtype]

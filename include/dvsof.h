@@ -255,6 +255,9 @@ typedef struct {
     const float *p; /* dense tensor [B,H,W,C] (NHWC) or [B,C,H,W] (NCHW) */
     int C;
     int layout; /* DVSOF_NHWC | DVSOF_NCHW */
+    const void *p16; /* optional bf16 twin of an NHWC tensor (same shape, same
+                        values rounded to bf16): read instead of p by the
+                        matrix-core kernels in mfma mode 3 */
 } dvsof_src_t;
 
 /*
@@ -277,7 +280,16 @@ typedef struct {
                  bf16 in registers, v_mfma_f32_32x32x16_bf16, f32 accumulate;
                  2: operands split into bf16 hi + lo, products hi*hi + hi*lo +
                  lo*hi (the dropped lo*lo term is 2^-16 relative).
-                 Every tensor stays f32 in memory in all modes. */
+                 Every tensor stays f32 in memory in modes 0-2.
+                 3: bf16 TWINS -- like 1, but the forward / data-gradient
+                 kernels stream bf16 copies of their NHWC operands (src[i].p16,
+                 gout16) and of the prepared weights (w16) through LDS: half
+                 the LDS-DMA bytes mode 1 is bound by, no conversion in the K
+                 loop.  Producers write the twin of their output next to the
+                 f32 tensor (y16, dst[i].p16, dvsof_flow_head_bwd's gx16); the
+                 weight gradient, the heads and the loss keep reading f32.
+                 Needs every NHWC source channel count % 32 == 0, else the
+                 call runs as mode 1. */
     void *scratch;        /* device scratch for layers that run as Winograd */
     size_t scratch_bytes; /* F(2x2,3x3) (dvsof_conv2d_scratch_bytes > 0); read by
                              dvsof_conv2d_fwd / _dgrad only, which return
@@ -288,6 +300,11 @@ typedef struct {
                              that kept that buffer intact passes it here and the
                              weight gradient skips its own input transform
                              (used when both run the same tile form) */
+    /* mode 3 only (NULL otherwise) */
+    void *y16;           /* dvsof_conv2d_fwd: bf16 twin of y, written */
+    const void *w16;     /* bf16 twin of the weight argument of the call
+                            (dvsof_to_bf16 of the prepared form) */
+    const void *gout16;  /* dvsof_conv2d_dgrad: bf16 twin of gout */
 } dvsof_conv_desc_t;
 
 /*
@@ -341,6 +358,7 @@ typedef struct {
     const float *addend2; /* optional second addend */
     const float *actsrc; /* optional: p *= act'(actsrc), the producer's y
                             (ReLU) or z (Mish): yields its dz directly */
+    void *p16;           /* optional bf16 twin of p, written (mode 3) */
 } dvsof_grad_dst_t;
 
 /*
@@ -394,7 +412,12 @@ int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow,
                         const float *gx_in, const float *actsrc, int act,
                         float *gx, float *dw, float *dbias, int B, int H, int W,
                         int C, void *workspace, size_t workspace_bytes,
+                        void *gx16 /* optional bf16 twin of gx, written */,
                         void *stream);
+
+/* dst[i] = bf16(src[i]) (round to nearest even), n elements: the bf16 twins of
+ * the prepared weights for mfma mode 3 */
+int dvsof_to_bf16(const float *src, void *dst, size_t n, void *stream);
 
 /* dz = dy * act'(actsrc), n elements (dz may alias dy) */
 int dvsof_act_bwd(const float *dy, const float *actsrc, int act, float *dz,

@@ -56,6 +56,10 @@ def cfg2_case():
     # residual layers, which run as Winograd F(2x2) in this mode)
     ('bf16x3', 1e-3, 1e-2, 0.9999),
     ('bf16', 3e-2, 0.2, 0.98),          # the bf16 bars of test_gpu_model.py:289-311
+    # bf16 twins: activations / gradients / prepared weights ALSO stored as bf16
+    # and streamed through LDS in that form by the forward / data-gradient
+    # kernels (one more rounding per tensor than 'bf16': the stored twin)
+    ('bf16s', 3e-2, 0.25, 0.97),
 ])
 def test_config2_workload_in_bf16_modes_vs_float64(cfg2_case, dtype, flow_tol, grad_rel,
                                                   grad_cos):

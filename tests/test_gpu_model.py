@@ -373,7 +373,34 @@ def test_bf16x3_mode_is_f32_accurate():
         assert float((p.grad - q.grad).norm()) <= 1e-3 * float(p.grad.norm()) + 1e-9
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16x3', 'bf16'])
+def test_bf16_twins_mode_matches_the_bf16_operand_mode():
+    """compute_dtype='bf16s' (bf16 twins of activations, gradients and
+    prepared weights streamed through LDS) against 'bf16' (f32 tensors,
+    operands rounded in registers).  The forward of a layer is the SAME
+    arithmetic in both -- bf16(x) * bf16(w) accumulated in f32 -- so flows agree
+    to accumulation order; the data gradients differ by one bf16 rounding of
+    the stored gradient per layer.  Mish exercises the z twin-less path too."""
+    from dvs_of_training_framework_amd.options import Mish
+    from dvs_of_training_framework_amd.predictor import Predictor
+    for act in (torch.nn.ReLU(), Mish()):
+        torch.manual_seed(13)
+        a = Predictor(5, activation=act, compute_dtype='bf16').cuda()
+        b = Predictor(5, activation=act, compute_dtype='bf16s').cuda()
+        b.load_state_dict(a.state_dict())
+        x = torch.randn(2, 5, 64, 96, device='cuda')
+        fa, fb = a(x), b(x)
+        seeds = [torch.randn_like(f) for f in fa]
+        torch.autograd.backward(fa, seeds)
+        torch.autograd.backward(fb, seeds)
+        for u, v in zip(fa, fb):
+            assert float((u - v).norm()) <= 2e-3 * float(u.norm())
+        for (n, p), q in zip(a.named_parameters(), b.parameters()):
+            assert bool(torch.isfinite(q.grad).all()), n
+            rel = float((p.grad - q.grad).norm()) / (float(p.grad.norm()) + 1e-12)
+            assert rel <= 5e-2, (n, rel)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16x3', 'bf16', 'bf16s'])
 def test_training_reduces_the_loss_on_a_fixed_batch(dtype):
     """End-to-end sanity of the whole step (voxelise, predictor, fused loss,
     two-stream backward, fused AdamW): 40 steps on one batch lower the loss."""
