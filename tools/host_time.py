@@ -26,7 +26,20 @@ def main():
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f'host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, with drain {1e3 * (t2 - t0) / n:.3f} ms/step')
+    print(f'eager: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, with drain {1e3 * (t2 - t0) / n:.3f} ms/step')
+    # the same step as one hipGraph replay (capture.CapturedTrainStep)
+    a.graph = True
+    for _ in range(3):
+        h.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        h.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f'graph: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, with drain {1e3 * (t2 - t0) / n:.3f} ms/step')
+    h.suspend_graph()
     import cProfile
     import pstats
     pr = cProfile.Profile()
