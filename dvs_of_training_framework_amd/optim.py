@@ -208,18 +208,24 @@ class FusedAdamW(_FusedBase):
         step counters alone (capturing enqueues nothing; ``advance`` counts).
         The table is allocated once: a captured graph keeps its address."""
         if getattr(self, '_dyn', None) is None:
-            self._dyn = torch.zeros(len(self.param_groups), 4,
-                                    dtype=torch.float32, device=device)
+            ng = len(self.param_groups)
+            self._dyn = torch.zeros(ng, 4, dtype=torch.float32, device=device)
+            # ring of pinned staging rows: an async copy reads its row when the
+            # stream gets there, so a row is rewritten only after its copy's
+            # event has completed (the host runs several steps ahead)
+            self._dyn_ring = [(torch.zeros(ng, 4, dtype=torch.float32).pin_memory(),
+                               torch.cuda.Event()) for _ in range(8)]
+            self._dyn_next = 0
         self._use_dyn = True
 
     def advance(self):
         """Before every replay: count the step and refresh {lr, lr/bc1,
-        sqrt(bc2)} of every group.  The host values travel through a pageable
-        staging copy (complete when the call returns), so the next call may
-        overwrite them while this step is still queued."""
-        rows = []
+        sqrt(bc2)} of every group with one small asynchronous copy."""
+        host, done = self._dyn_ring[self._dyn_next]
+        self._dyn_next = (self._dyn_next + 1) % len(self._dyn_ring)
+        done.synchronize()      # the copy that last read this row (8 steps ago)
         buf = (ctypes.c_float * 3)()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             steps = set()
             for p in group['params']:
                 st = self._state(p)
@@ -229,8 +235,9 @@ class FusedAdamW(_FusedBase):
             b1, b2 = group['betas']
             _lib.lib().dvsof_adamw_dynamic(float(group['lr']), float(b1),
                                            float(b2), steps.pop(), buf)
-            rows.append([buf[0], buf[1], buf[2], 0.0])
-        self._dyn.copy_(torch.tensor(rows, dtype=torch.float32))
+            host[gi, 0], host[gi, 1], host[gi, 2] = buf[0], buf[1], buf[2]
+        self._dyn.copy_(host, non_blocking=True)
+        done.record()
 
     def end_capture(self):
         """Back to eager steps (the table stays: a graph may still use it)."""
