@@ -31,6 +31,10 @@ class LossScale(ctypes.Structure):
 _SIGNATURES = {
     'dvsof_version': (_i, []),
     'dvsof_error_string': (ctypes.c_char_p, [_i]),
+    'dvsof_comm_unique_id': (_i, [_vp]),
+    'dvsof_comm_create': (_i, [ctypes.POINTER(_vp), _i, _i, _vp]),
+    'dvsof_comm_destroy': (_i, [_vp]),
+    'dvsof_allreduce_bucket': (_i, [_vp, _vp, _sz, _vp]),
     'dvsof_count_image': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     'dvsof_voxelize_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                 _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

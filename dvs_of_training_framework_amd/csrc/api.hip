@@ -11,6 +11,7 @@ const char *dvsof_error_string(int code)
     case DVSOF_OK: return "ok";
     case DVSOF_EINVAL: return "invalid argument (shape, null pointer or unsupported size)";
     case DVSOF_ENOSPACE: return "workspace too small";
+    case DVSOF_ECOMM: return "RCCL is missing or a communicator / collective call failed";
     default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -1,0 +1,98 @@
+// Gradient-bucket all-reduce over RCCL / xGMI behind the C ABI
+// (dvsof_allreduce_bucket).
+//
+// The reference has no collective at all (single process);
+// this is the data-parallel exchange of the build: every rank averages each
+// gradient bucket in place as soon as the backward has produced it, on a side
+// stream (parallel.GradReducer drives it).  The Python path normally uses
+// torch.distributed's process group (backend 'nccl' = RCCL); these entry
+// points give a binding WITHOUT torch.distributed the same exchange.
+//
+// librccl is opened lazily (dlopen): the library loads, and every other entry
+// point works, on a machine without RCCL.
+#include "common.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    if (r.handle || r.ok) return r;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return r;
+    r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.handle, "ncclGetUniqueId");
+    r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(r.handle, "ncclCommInitRank");
+    r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.handle, "ncclCommDestroy");
+    r.all_reduce = (decltype(r.all_reduce))dlsym(r.handle, "ncclAllReduce");
+    r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce;
+    return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvsof_comm_unique_id(void *host_id128)
+{
+    if (!host_id128) return DVSOF_EINVAL;
+    Rccl &r = rccl();
+    if (!r.ok) return DVSOF_ECOMM;
+    ncclUniqueId id;
+    if (r.get_unique_id(&id) != ncclSuccess) return DVSOF_ECOMM;
+    static_assert(sizeof(id) == DVSOF_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(host_id128, &id, sizeof(id));
+    return DVSOF_OK;
+}
+
+int dvsof_comm_create(void **comm, int world_size, int rank, const void *host_id128)
+{
+    if (!comm || !host_id128 || world_size < 1 || rank < 0 || rank >= world_size) return DVSOF_EINVAL;
+    Rccl &r = rccl();
+    if (!r.ok) return DVSOF_ECOMM;
+    ncclUniqueId id;
+    memcpy(&id, host_id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    if (r.comm_init_rank(&c, world_size, id, rank) != ncclSuccess) return DVSOF_ECOMM;
+    *comm = (void *)c;
+    return DVSOF_OK;
+}
+
+int dvsof_comm_destroy(void *comm)
+{
+    if (!comm) return DVSOF_EINVAL;
+    Rccl &r = rccl();
+    if (!r.ok) return DVSOF_ECOMM;
+    return r.comm_destroy((ncclComm_t)comm) == ncclSuccess ? DVSOF_OK : DVSOF_ECOMM;
+}
+
+int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream)
+{
+    if (!comm || !bucket) return DVSOF_EINVAL;
+    if (n == 0) return DVSOF_OK;
+    Rccl &r = rccl();
+    if (!r.ok) return DVSOF_ECOMM;
+    // in place, average over the ranks: the mean of per-rank gradients is the
+    // global-batch gradient (equal per-rank batch)
+    return r.all_reduce(bucket, bucket, n, ncclFloat32, ncclAvg, (ncclComm_t)comm, as_stream(stream)) ==
+                   ncclSuccess
+               ? DVSOF_OK
+               : DVSOF_ECOMM;
+}
+
+}  // extern "C"

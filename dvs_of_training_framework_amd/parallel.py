@@ -59,15 +59,48 @@ def init_distributed(device_type='cuda'):
 
 
 class GradReducer:
-    """Averages gradient buckets across ranks, overlapped with backward."""
+    """Averages gradient buckets across ranks, overlapped with backward.
 
-    def __init__(self, group=None):
+    direct=True: the collective is ``dvsof_allreduce_bucket`` of the C ABI (its
+    own RCCL communicator, created here from a unique id that rank 0 shares
+    through the process group) instead of ``torch.distributed.all_reduce`` --
+    the same exchange, enqueued straight on the exchange stream."""
+
+    def __init__(self, group=None, direct=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.enabled = True          # False on non-boundary micro-batches
         self.pending = []
         self._side = None
         self.bytes_reduced = 0
+        self._comm = None
+        if direct:
+            self._comm = self._make_comm()
+
+    def _make_comm(self):
+        import ctypes
+        from . import _lib
+        lib = _lib.lib()
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.dvsof_comm_unique_id(ident), 'dvsof_comm_unique_id')
+        if self.world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        with _stdout_to_stderr():        # RCCL's banner, as in init_distributed
+            _lib.check(lib.dvsof_comm_create(ctypes.byref(comm), self.world, rank,
+                                             ident), 'dvsof_comm_create')
+        return comm
+
+    def close(self):
+        if self._comm is not None:
+            from . import _lib
+            torch.cuda.synchronize()
+            _lib.lib().dvsof_comm_destroy(self._comm)
+            self._comm = None
 
     def _side_stream(self, device):
         if self._side is None:
@@ -88,7 +121,22 @@ class GradReducer:
                 after()
             return
         self.bytes_reduced += flat.numel() * flat.element_size()
-        if flat.is_cuda:
+        if flat.is_cuda and self._comm is not None:
+            from . import _lib
+            ready = torch.cuda.Event()
+            ready.record()
+            side = self._side_stream(flat.device)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                _lib.check(_lib.lib().dvsof_allreduce_bucket(
+                    self._comm, flat.data_ptr(), flat.numel(), _lib.stream()),
+                    'dvsof_allreduce_bucket')
+                if after is not None:    # stream-ordered behind the collective
+                    after()
+            self._keep = getattr(self, '_keep', [])
+            self._keep.append(flat)
+            self._touched = True
+        elif flat.is_cuda:
             ready = torch.cuda.Event()
             ready.record()
             side = self._side_stream(flat.device)
@@ -115,6 +163,7 @@ class GradReducer:
                 if len(item) > 3 and item[3] is not None:
                     item[3]()
         self.pending = []
+        self._keep = []
         if getattr(self, '_touched', False) and self._side is not None:
             # updates enqueued behind the collectives on the exchange stream
             torch.cuda.current_stream().wait_stream(self._side)

@@ -33,7 +33,8 @@ extern "C" {
 enum {
     DVSOF_OK = 0,
     DVSOF_EINVAL = -1,  /* bad shape / null pointer / unsupported size */
-    DVSOF_ENOSPACE = -2 /* workspace too small */
+    DVSOF_ENOSPACE = -2, /* workspace too small */
+    DVSOF_ECOMM = -3     /* RCCL missing or a collective / communicator call failed */
 };
 
 int dvsof_version(void);
@@ -485,6 +486,25 @@ int dvsof_radam_step(const uint64_t *ptrs, const int64_t *sizes,
 
 /* Gradient centralisation (Ranger): grad[r][:] -= mean(grad[r][:]). */
 int dvsof_grad_centralize(float *grad, int rows, int row_len, void *stream);
+
+/* ------------------------------------------------------------------ *
+ * Data-parallel gradient exchange (RCCL over xGMI).  The reference is single
+ * process (no torch.distributed / NCCL use anywhere); this
+ * is the one collective of the build: the average of a gradient bucket over
+ * the ranks, in place, enqueued on `stream` (the caller's exchange stream,
+ * gated by an event behind the bucket's last weight gradient and joined
+ * before the optimizer step: parallel.GradReducer).  One process per GPU;
+ * librccl is opened on first use (DVSOF_ECOMM when it is absent).
+ *   rank 0:   dvsof_comm_unique_id(id)  -> send the 128 bytes to every rank
+ *   all:      dvsof_comm_create(&comm, world, rank, id)   (current HIP device)
+ *   per step: dvsof_allreduce_bucket(comm, bucket, n, stream) per bucket
+ * ------------------------------------------------------------------ */
+#define DVSOF_COMM_ID_BYTES 128
+int dvsof_comm_unique_id(void *host_id128);
+int dvsof_comm_create(void **comm, int world_size, int rank,
+                      const void *host_id128);
+int dvsof_comm_destroy(void *comm);
+int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,12 @@ def main():
     g_red, w_red = run(red, True, False, steps=2)
     g_red2, w_red2 = run(red, True, False, steps=2)
     _, w_fused = run(red, True, True, steps=2)
+    # the same exchange through the C ABI's own communicator
+    direct = parallel.GradReducer(direct=True)
+    g_dir, w_dir = run(direct, True, False, steps=2)
+    _, w_dir_fused = run(direct, True, True, steps=2)
+    direct_bytes = direct.bytes_reduced
+    direct.close()
     same = lambda a, b: all(torch.equal(u, v) for u, v in zip(a, b))  # noqa: E731
     nparam = sum(p.numel() for p in fresh().parameters())
     print(json.dumps({
@@ -72,7 +78,10 @@ def main():
         'bytes_reduced': red.bytes_reduced, 'grad_bytes': 4 * nparam,
         'grads_bit_identical': same(g_plain, g_red) and same(w_plain, w_red),
         'repeat_bit_identical': same(g_red, g_red2) and same(w_red, w_red2),
-        'fused_weights_bit_identical': same(w_plain, w_fused)}), flush=True)
+        'fused_weights_bit_identical': same(w_plain, w_fused),
+        'direct_bit_identical': same(g_plain, g_dir) and same(w_plain, w_dir) and
+        same(w_plain, w_dir_fused),
+        'direct_bytes': direct_bytes}), flush=True)
     dist.destroy_process_group()
 
 

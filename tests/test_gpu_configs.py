@@ -238,3 +238,6 @@ def test_rccl_bucket_path_is_bit_identical_in_a_one_rank_group():
     assert res['grads_bit_identical'], res
     assert res['fused_weights_bit_identical'], res
     assert res['repeat_bit_identical'], res
+    # dvsof_allreduce_bucket: the C ABI's own RCCL communicator
+    assert res['direct_bit_identical'], res
+    assert res['direct_bytes'] == res['grad_bytes'] * 4
