@@ -424,7 +424,8 @@ def main():
     h = Harness(a, rank, device)
     if world > 1 or os.environ.get('DVSOF_FORCE_DIST') == '1':
         parallel.broadcast_parameters(h.model)
-        h.reducer = parallel.GradReducer()
+        # DVSOF_DIRECT_RCCL=1: the C ABI's own communicator (dvsof_allreduce_bucket)
+        h.reducer = parallel.GradReducer(direct=os.environ.get('DVSOF_DIRECT_RCCL') == '1')
         h.model.predictor.reducer = h.reducer
 
     def barrier():

@@ -252,15 +252,22 @@ class _PredictorFn(torch.autograd.Function):
             main.wait_event(ctx.dg_ready)
         keep = []
 
+        # DVSOF_WGRAD_STREAMS=n (default 1): weight gradients dealt round-robin
+        # to n side streams (they are independent of each other)
+        sides = [side] + (ctx.module._extra_streams(dev) if side is not None else [])
+        turn = [0]
+
         def wgrad(desc, gz, gw, gb, unit):
             if side is None:
                 C.conv_wgrad(desc, gz, gw, gb)
                 finish(unit)
                 return
+            s_ = sides[turn[0] % len(sides)]
+            turn[0] += 1
             ready = torch.cuda.Event()
             ready.record(main)
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
+            s_.wait_event(ready)
+            with torch.cuda.stream(s_):
                 C.conv_wgrad(desc, gz, gw, gb)
                 finish(unit)
             keep.append(gz)
@@ -351,7 +358,8 @@ class _PredictorFn(torch.autograd.Function):
                 C.conv_wgrad(desc, g, gw, gb)
                 finish(unit)
         if side is not None:
-            main.wait_stream(side)
+            for s_ in sides:
+                main.wait_stream(s_)
         del keep
         ctx.L = None
         return (None,) * (3 + len(params))
@@ -419,6 +427,14 @@ class Predictor(nn.Module):
                 self._wg_stream.device != dev:
             self._wg_stream = torch.cuda.Stream(device=dev)
         return self._wg_stream
+
+    def _extra_streams(self, dev):
+        n = int(os.environ.get('DVSOF_WGRAD_STREAMS', '1')) - 1
+        have = getattr(self, '_wg_extra', [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=dev))
+        self._wg_extra = have
+        return have[:max(n, 0)]
 
     def _buckets(self, params):
         dev = params[0].device
