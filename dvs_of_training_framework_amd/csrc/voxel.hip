@@ -105,11 +105,19 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t, const
 //     8-byte records {local pixel | lower bin | sign, fraction (exact f32)}.
 //     Buckets have a fixed capacity (2x the mean + slack); events that do not
 //     fit go to an overflow list (none for well-spread data).
-//   pass 2 (vox_tile_kernel): one workgroup per (sample, 1024-pixel tile): zero the
-//     [C][1024] tile in LDS, ds_add_f32 the bucket's records, then the
-//     overflow records that belong to this tile (the list is empty unless the
-//     events pile up in a few tiles), store the tile with coalesced rows.
-//     No global float atomics at all.
+//   pass 2 (vox_tile_kernel): one workgroup per (sample, tile of 1024 or 512
+//     pixels): zero the [C][tile] accumulators in LDS, add the bucket's
+//     records, then the overflow records that belong to this tile (the list
+//     is empty unless the events pile up in a few tiles), store the tile with
+//     coalesced rows.  No global float atomics at all -- and no LDS float
+//     atomics either: ds_add_f32 measured ~150 cycles per wave instruction on
+//     gfx950 (33 of the 59 us of this pass at batch 64), integer LDS atomics
+//     are free next to the loads.  The accumulators are 64-bit FIXED POINT
+//     (2^-32): an event adds sign * (2^32 - F) and sign * F, F = trunc(f * 2^32)
+//     exactly, so a voxel is the exact sum of its weights to 2^-32 per event,
+//     the two halves of an event add up to exactly +-1, and the result does
+//     not depend on the order of additions: the tiled path is bitwise
+//     reproducible.
 //   The control words (bucket cursors, overflow count, finished-tile count)
 //   are SELF-CLEANING: every tile workgroup zeroes its cursor after reading
 //   it, the last one to finish zeroes the two counters.  A workspace whose
@@ -120,13 +128,17 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t, const
 // ===========================================================================
 namespace {
 
-// A tile is 1024 pixels (10-bit local index), 2^lx wide and 2^(10-lx) high;
+// A tile is 2^lp pixels (lp = 10, or 9 when many bins would not leave room for
+// several workgroups' 8-byte accumulators in LDS), 2^lx wide and 2^(lp-lx) high;
 // lx is chosen per call (v2_plan): as wide as the frame allows, so that a
 // workgroup stores long contiguous runs of every output row it owns.
-constexpr int VPX = 1024;
-// events per thread in pass 1: 4 up to ~2 M events, 8 above (measured: 24.0 vs 26.3 us at
-// 0.5 M events, 111 vs 108 us at 4.2 M, 137 vs 121 us at 4 M events on 512 x 512 x 12)
+constexpr int VPX_MAX = 1024;
+// events per thread in pass 1: 4 up to ~2 M events, 8 above, 16 from ~3 M (measured, whole
+// path, EPT 4 / 8 / 16: 16.8 / 19.2 / 24.7 us at 0.5 M events, 79.0 / 76.4 / 71.3 us at 4.2 M,
+// 105.9 / 82.5 / 72.6 us at 4 M events on 512 x 512 x 12)
 constexpr int64_t EPT8_FROM = 1 << 21;
+// 16 from ~4 M events: half the bucket-cursor atomics, twice as long record runs per tile
+constexpr int64_t EPT16_FROM = 3 << 20;
 constexpr int V2_MAX_TILES = 8192;
 
 struct VoxV2 {
@@ -141,7 +153,7 @@ struct VoxV2 {
     int enc;
     const float *t, *t0, *t1;
     int64_t n;
-    int B, C, H, W, TX, TY, ntile, cap, lx;   // lx = log2(tile width)
+    int B, C, H, W, TX, TY, ntile, cap, lx, lp;   // lx = log2(tile width), lp = log2(tile pixels)
     int32_t *cursor;      // [ntile] events reserved per tile (may exceed cap)
     int32_t *ovf_count;   // [1] overflow records
     int32_t *ovf_tiles;   // [1] tiles whose bucket overflowed
@@ -204,9 +216,9 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
                     c0 = min((int)floorf(tn), P.C - 1);
                     frac[k] = tn - (float)c0;
                     l = (int64_t)((((size_t)b * P.C + c0) * P.H + (size_t)yi) * P.W + (size_t)xi);
-                    const int ty = (int)yi >> (10 - P.lx), tx = (int)xi >> P.lx;
+                    const int ty = (int)yi >> (P.lp - P.lx), tx = (int)xi >> P.lx;
                     if (!zero) tile[k] = ((int)b * P.TY + ty) * P.TX + tx;
-                    key[k] = (unsigned)((((int)yi - (ty << (10 - P.lx))) << P.lx) + ((int)xi - (tx << P.lx))) |
+                    key[k] = (unsigned)((((int)yi - (ty << (P.lp - P.lx))) << P.lx) + ((int)xi - (tx << P.lx))) |
                              ((unsigned)c0 << 10) | (neg ? 0x80000000u : 0u);
                 }
             }
@@ -261,29 +273,45 @@ __global__ __launch_bounds__(NT) void vox_bucket_kernel(const VoxV2 P)
     }
 }
 
-__device__ __forceinline__ void tile_add(float *tl, unsigned key, float f, int C)
+// one event into the tile's 2^-32 fixed-point accumulators (integer LDS atomics)
+__device__ __forceinline__ void tile_add(unsigned long long *tl, unsigned key, float f, int C, int lp)
 {
     const int pix = key & 0x3ff, c0 = (key >> 10) & 0x3ff;
-    const float p = (key & 0x80000000u) ? -1.f : 1.f;
-    atomicAdd(&tl[c0 * VPX + pix], p * (1.f - f));
-    if (c0 + 1 < C) atomicAdd(&tl[(c0 + 1) * VPX + pix], p * f);
+    const unsigned long long F = (unsigned long long)(unsigned)(f * 4294967296.f);   // f in [0,1): exact
+    const unsigned long long w1 = F, w0 = 4294967296ull - F;
+    const bool neg = key & 0x80000000u;
+    // two's complement: adding (0 - w) subtracts
+    atomicAdd(&tl[(c0 << lp) + pix], neg ? 0ull - w0 : w0);
+    if (c0 + 1 < C) atomicAdd(&tl[((c0 + 1) << lp) + pix], neg ? 0ull - w1 : w1);
 }
 
 __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
 {
-    extern __shared__ float tl[];        // [C][VTY][VTX]
+    extern __shared__ unsigned long long tl[];   // [C][2^lp] fixed-point accumulators
     const int tile = blockIdx.x;
     const int tx = tile % P.TX, ty = (tile / P.TX) % P.TY, b = tile / (P.TX * P.TY);
-    const int nel = P.C * VPX;
+    const int nel = P.C << P.lp;
+    // One memory round trip instead of two: the first 4*NT records are fetched
+    // SPECULATIVELY (the bucket's address does not depend on its fill count)
+    // together with the count, while the LDS tile is being zeroed.
+    const uint2 *rec = P.records + (size_t)tile * P.cap;
     const int reserved = P.cursor[tile];
-    for (int i = threadIdx.x * 4; i < nel; i += NT * 4) *(float4 *)(tl + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 r0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = u * NT + (int)threadIdx.x;
+        r0[u] = i < P.cap ? rec[i] : make_uint2(0u, 0u);
+    }
+    for (int i = threadIdx.x * 2; i < nel; i += NT * 2) *(ulonglong2 *)(tl + i) = make_ulonglong2(0ull, 0ull);
     const int cnt = min(reserved, P.cap);
     __syncthreads();
     if (threadIdx.x == 0) P.cursor[tile] = 0;       // self-cleaning control words
-    const uint2 *rec = P.records + (size_t)tile * P.cap;
-    // 4 record loads in flight per thread (a rolled loop is one dependent
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (u * NT + (int)threadIdx.x < cnt) tile_add(tl, r0[u].x, __uint_as_float(r0[u].y), P.C, P.lp);
+    // the rest, 4 loads in flight per thread (a rolled loop is one dependent
     // memory round trip per iteration)
-    for (int i0 = 0; i0 < cnt; i0 += 4 * NT) {
+    for (int i0 = 4 * NT; i0 < cnt; i0 += 4 * NT) {
         uint2 r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -292,7 +320,7 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * NT + (int)threadIdx.x < cnt) tile_add(tl, r[u].x, __uint_as_float(r[u].y), P.C);
+            if (i0 + u * NT + (int)threadIdx.x < cnt) tile_add(tl, r[u].x, __uint_as_float(r[u].y), P.C, P.lp);
     }
     // events that did not fit this tile's bucket (skewed inputs only): they
     // are on the overflow list among those of the other full buckets
@@ -301,19 +329,24 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
         const int64_t novf = min((int64_t)*P.ovf_count, P.ovf_cap);
         for (int64_t i = threadIdx.x; i < novf; i += NT) {
             const int4 r = P.ovf[i];
-            if (r.x == tile) tile_add(tl, (unsigned)r.y, __int_as_float(r.z), P.C);
+            if (r.x == tile) tile_add(tl, (unsigned)r.y, __int_as_float(r.z), P.C, P.lp);
         }
     }
     __syncthreads();
     // 16 bytes per lane along a tile row: full 128-byte lines, long runs for wide tiles
-    const int y0 = ty << (10 - P.lx), x0 = tx << P.lx;
+    const int y0 = ty << (P.lp - P.lx), x0 = tx << P.lx;
     const bool vec = (P.W & 3) == 0 && ((uintptr_t)P.out & 15) == 0;
     for (int i = threadIdx.x * 4; i < nel; i += NT * 4) {
-        const int c = i / VPX, r = i - c * VPX, ly = r >> P.lx, lx = r - (ly << P.lx);
+        const int c = i >> P.lp, r = i - (c << P.lp), ly = r >> P.lx, lx = r - (ly << P.lx);
         const int y = y0 + ly, x = x0 + lx;
         if (y >= P.H || x >= P.W) continue;
         float *o = P.out + (((size_t)b * P.C + c) * P.H + y) * P.W + x;
-        const float4 v = *(const float4 *)(tl + i);
+        float4 v;
+        // signed 2^-32 fixed point -> the correctly rounded float of the exact sum
+        v.x = (float)((double)(long long)tl[i] * 2.3283064365386963e-10);
+        v.y = (float)((double)(long long)tl[i + 1] * 2.3283064365386963e-10);
+        v.z = (float)((double)(long long)tl[i + 2] * 2.3283064365386963e-10);
+        v.w = (float)((double)(long long)tl[i + 3] * 2.3283064365386963e-10);
         if (vec) {          // W % 4 == 0 and x % 4 == 0: the quad is inside the row
             *(float4 *)o = v;
         } else {
@@ -334,17 +367,21 @@ __global__ __launch_bounds__(NT) void vox_tile_kernel(const VoxV2 P)
 
 bool v2_plan(int64_t n, int B, int C, int H, int W, VoxV2 &P)
 {
-    // tile width: the frame's width rounded up to a power of two, 64..1024
+    // tile: 1024 pixels, or 512 when C 8-byte accumulators per pixel would leave
+    // fewer than three workgroups per CU (160 KiB LDS)
+    const int lp = (size_t)C * 1024 * 8 > 52 * 1024 ? 9 : 10;
+    P.lp = lp;
+    // tile width: the frame's width rounded up to a power of two, 64..2^lp
     static const int lx_env = getenv("DVSOF_VOX_TILE_LOG2X") ? atoi(getenv("DVSOF_VOX_TILE_LOG2X")) : 0;
     int lx = 6;
-    while (lx < 10 && (1 << lx) < W) ++lx;
-    if (lx_env >= 2 && lx_env <= 10) lx = lx_env;
+    while (lx < lp && (1 << lx) < W) ++lx;
+    if (lx_env >= 2 && lx_env <= lp) lx = lx_env;
     P.lx = lx;
-    const int vtx = 1 << lx, vty = 1 << (10 - lx);
+    const int vtx = 1 << lx, vty = 1 << (lp - lx);
     P.TX = (W + vtx - 1) / vtx;
     P.TY = (H + vty - 1) / vty;
     const int64_t nt = (int64_t)B * P.TX * P.TY;
-    if (nt > V2_MAX_TILES || (size_t)C * VPX * 4 > 150 * 1024 || C > 1023) return false;
+    if (nt > V2_MAX_TILES || ((size_t)C << lp) * 8 > 150 * 1024 || C > 1023) return false;
     P.ntile = (int)nt;
     int64_t cap = 2 * (n / nt) + 256;
     cap = (cap + 63) / 64 * 64;
@@ -380,14 +417,25 @@ int v2_launch(const VoxV2 &P, int flags, hipStream_t st)
     if (!(flags & DVSOF_VOX_WS_CLEAN))
         DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, v2_control_bytes(P), st));
     const int64_t n = P.n;
-    if (n >= EPT8_FROM)
+    static const int ept_env = getenv("DVSOF_VOX_EPT") ? atoi(getenv("DVSOF_VOX_EPT")) : 0;
+    if (ept_env == 16 || (ept_env == 0 && n >= EPT16_FROM))
+        hipLaunchKernelGGL(vox_bucket_kernel<16>, dim3((unsigned)((n + NT * 16 - 1) / (NT * 16))), dim3(NT),
+                           (size_t)P.ntile * 8, st, P);
+    else if (ept_env == 8 || (ept_env == 0 && n >= EPT8_FROM))
         hipLaunchKernelGGL(vox_bucket_kernel<8>, dim3((unsigned)((n + NT * 8 - 1) / (NT * 8))), dim3(NT),
                            (size_t)P.ntile * 8, st, P);
     else
         hipLaunchKernelGGL(vox_bucket_kernel<4>, dim3((unsigned)((n + NT * 4 - 1) / (NT * 4))), dim3(NT),
                            (size_t)P.ntile * 8, st, P);
     DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), (size_t)P.C * VPX * 4, st, P);
+    const size_t tile_lds = ((size_t)P.C << P.lp) * 8;
+    static bool attr_set = false;
+    if (tile_lds > 64 * 1024 && !attr_set) {
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)vox_tile_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(vox_tile_kernel, dim3(P.ntile), dim3(NT), tile_lds, st, P);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
