@@ -17,9 +17,38 @@ static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
-// Sum over the 64 lanes of a wave; result valid in lane 0.
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
+// Sum over the 64 lanes of a wave; the result is valid in EVERY lane.
+// 32-bit types: DPP row shifts + row broadcasts + one v_readlane, all VALU --
+// ds_bpermute (what __shfl compiles to) goes through the LDS crossbar and
+// measured ~12 us of a 97 us loss sweep for 42 of them per wave.
+//   row_shr:n   0x110 + n   lane i of a 16-lane row reads lane i - n (0 outside)
+//   row_bcast15 0x142       lane 15 of row r -> every lane of row r + 1
+//   row_bcast31 0x143       lane 31 -> every lane of rows 2, 3
+__device__ __forceinline__ int wave_sum_bits(int v, bool is_float)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto add = [&](int a, int b) -> int {
+        return is_float ? __builtin_bit_cast(int, __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b))
+                        : a + b;
+    };
+    v = add(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));
+    v = add(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));
+    v = add(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));
+    v = add(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // lane 15 of each row: row sum
+    v = add(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));  // rows 1, 3 += row 0, 2
+    v = add(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));  // rows 2, 3 += lane 31
+    return __builtin_amdgcn_readlane(v, 63);
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    return __builtin_bit_cast(float, wave_sum_bits(__builtin_bit_cast(int, v), true));
+}
+__device__ __forceinline__ int wave_sum(int v) { return wave_sum_bits(v, false); }
+// 64-bit: shuffle tree (only the few closing waves of a reduction use it); valid in lane 0
+__device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);

@@ -64,6 +64,8 @@ struct Params {
     float *terms, *loss_out;    // outputs of the folded reduction
     float wts[3], loss_scale;
     int strict_fences;          // agent-scope release/acquire fences around the counters
+    int dbg;                    // DVSOF_LOSS_DBG timing probes (results wrong by construction)
+    int fold;                   // 1: the sweep's last-arriving workgroups reduce; 0: loss_reduce_kernel does
 };
 
 __device__ __forceinline__ int find_scale(const Params &P, int bid)
@@ -139,59 +141,59 @@ __device__ __forceinline__ T observe(const T *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Group (k, n): add its tile records in a fixed order (double).  All 256
-// threads; the 7 sums end up in g[0..6] of thread `tid < 7`'s return value.
-__device__ __forceinline__ double group_sum(const Params &P, int k, int n, double (*sh)[7])
+// Group (k, n): add its tile records in a fixed order (double).  ONE wave
+// (the closing workgroup's wave 0: the other waves have retired); lane i < 7
+// returns sum i.
+__device__ __forceinline__ double group_sum(const Params &P, int k, int n)
 {
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
     const ScaleDev &S = P.s[k];
     const float *part = P.partials + ((size_t)S.block_begin + (size_t)n * S.tiles_per_sample) * NPART;
     double a[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int b = tid; b < S.tiles_per_sample; b += NT) {
+    for (int b = lane; b < S.tiles_per_sample; b += kWave) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) a[i] += (double)observe(part + (size_t)b * NPART + i);
     }
+    double mine = 0;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const double v = wave_sum(a[i]);
-        if (lane == 0) sh[wave][i] = v;
+        const double v = __shfl(wave_sum(a[i]), 0, kWave);
+        if (lane == i) mine = v;
     }
-    __syncthreads();
-    return tid < 7 ? (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]) : 0.0;
+    return mine;
 }
 
 // Last group: items (k, i), i < 5: global sums of photo + the four smoothness
 // directions; i == 5: border term = sum_n bs_n / (2 c_n N) (utils/loss.py:101,113).
-__device__ __forceinline__ void final_terms(const Params &P, double (*s_sum)[6])
+// One wave; lane 0 ends up with every item and writes the terms.
+__device__ __forceinline__ void final_terms(const Params &P)
 {
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    for (int item = wave; item < P.K * 6; item += NW) {
-        const int kk = item / 6, i = item - 6 * kk;
-        double a = 0;
-        for (int nn = lane; nn < P.N; nn += kWave) {
-            const double *g = P.group + ((size_t)kk * P.N + nn) * NGROUP;
-            if (i < 5) {
-                a += observe(g + i);
-            } else {
-                const double bs = observe(g + 5), c = observe(g + 6);
-                if (c > 0) a += bs / (2.0 * c * (double)P.N);
+    const int lane = threadIdx.x & (kWave - 1);
+    double total[3] = {0, 0, 0};
+    for (int kk = 0; kk < P.K; ++kk) {
+        double a6[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double a = 0;
+            for (int nn = lane; nn < P.N; nn += kWave) {
+                const double *g = P.group + ((size_t)kk * P.N + nn) * NGROUP;
+                if (i < 5) {
+                    a += observe(g + i);
+                } else {
+                    const double bs = observe(g + 5), c = observe(g + 6);
+                    if (c > 0) a += bs / (2.0 * c * (double)P.N);
+                }
             }
+            a6[i] = wave_sum(a);
         }
-        a = wave_sum(a);
-        if (lane == 0) s_sum[kk][i] = a;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double total[3] = {0, 0, 0};
-        for (int kk = 0; kk < P.K; ++kk) {
+        if (lane == 0) {
             const ScaleDev &S = P.s[kk];
-            const double *a = s_sum[kk];
             // empty crops contribute 0 (utils/loss.py:29-30)
-            const double sm = ((S.c_smooth[0] > 0 ? a[1] / S.c_smooth[0] : 0) +
-                               (S.c_smooth[1] > 0 ? a[2] / S.c_smooth[1] : 0) +
-                               (S.c_smooth[2] > 0 ? (a[3] + a[4]) / S.c_smooth[2] : 0)) / 4.0;
-            const double ph = a[0] / ((double)P.N * S.h * S.w);
-            const double border = a[5];
+            const double sm = ((S.c_smooth[0] > 0 ? a6[1] / S.c_smooth[0] : 0) +
+                               (S.c_smooth[1] > 0 ? a6[2] / S.c_smooth[1] : 0) +
+                               (S.c_smooth[2] > 0 ? (a6[3] + a6[4]) / S.c_smooth[2] : 0)) / 4.0;
+            const double ph = a6[0] / ((double)P.N * S.h * S.w);
+            const double border = a6[5];
             P.terms[0 * P.K + kk] = (float)sm;
             P.terms[1 * P.K + kk] = (float)ph;
             P.terms[2 * P.K + kk] = (float)border;
@@ -199,10 +201,10 @@ __device__ __forceinline__ void final_terms(const Params &P, double (*s_sum)[6])
             total[1] += ph;
             total[2] += border;
         }
-        if (P.loss_out)  // combined_loss, utils/training.py:23
-            P.loss_out[0] = (float)((P.wts[0] * total[0] + P.wts[1] * total[1] + P.wts[2] * total[2]) /
-                                    (double)P.K * (double)P.loss_scale);
     }
+    if (lane == 0 && P.loss_out)  // combined_loss, utils/training.py:23
+        P.loss_out[0] = (float)((P.wts[0] * total[0] + P.wts[1] * total[1] + P.wts[2] * total[2]) /
+                                (double)P.K * (double)P.loss_scale);
 }
 
 template <bool FWD, bool BWD>
@@ -211,9 +213,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     __shared__ float sF[2][LH][LW];
     __shared__ float sE[NW][2][12];      // left-edge column derivatives, per wave
     __shared__ float red[NW][NPART];
-    __shared__ int s_flag, s_cnt[NW];
-    __shared__ double s_dbl[NW][7];
-    __shared__ double s_sum[DVSOF_MAX_SCALES][6];
+    __shared__ int s_cnt[NW];
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int bid = blockIdx.x;
@@ -316,11 +316,15 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
         m11[j] = mv * vy1 * vx1;
         const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
         const int ya = min(max(y0, 0), h - 1) * w, yb = min(max(y0 + 1, 0), h - 1) * w;
+        if (P.dbg & 4) {        // probe: no gathers
+            nwv[j] = nev[j] = swv[j] = sev[j] = prv[j] = u;
+        } else {
         nwv[j] = I1[ya + xa];
         nev[j] = I1[ya + xb];
         swv[j] = I1[yb + xa];
         sev[j] = I1[yb + xb];
         prv[j] = I0[min(y, h - 1) * w + xc];
+        }
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     // photometric + out-of-border, utils/loss.py:58-74, 96-119
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        if (!valid[j]) continue;
+        if (!valid[j] || (P.dbg & 2)) continue;
         const float ax = axv[j], ay = ayv[j], cx = 1.f - ax, cy = 1.f - ay;
         const float nw = nwv[j], ne = nev[j], sw = swv[j], se = sev[j];
         const float warped = nw * cx * cy + ne * ax * cy + sw * cx * ay + se * ax * ay;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     // Branch-free: the LDS halo is zero-filled outside the frame, so every pair
     // can be evaluated and then multiplied by its 0/1 validity.  The two flow
     // channels of a pair go through the arithmetic together (packed f32).
-    {
+    if (!(P.dbg & 1)) {
         const float mx = x < w ? 1.f : 0.f, mxr = x + 1 < w ? 1.f : 0.f;
         float mrow[6];                     // rows -1..4 of the strip inside the frame
 #pragma unroll
@@ -449,7 +453,14 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
             }
         }
     }
-    if (BWD) {
+    // ---- tail.  Waves 1..3 store their gradients and RETIRE; wave 0 alone
+    // publishes the workgroup's sums, bumps the arrival counter, stores its
+    // own gradients while that atomic is in flight, and -- if it was the last
+    // of its group / the last group -- reduces with its 64 lanes.  (With the
+    // whole workgroup waiting for wave 0's atomic, every workgroup held its
+    // four wave slots for a memory round trip longer: 30 of 136 us at batch 64.)
+    auto store_grads = [&]() {
+        if (!BWD || (P.dbg & 8)) return;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             if (!valid[j]) continue;
@@ -457,35 +468,70 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
             G[0] = gu[j];
             G[hw] = gv[j];
         }
+    };
+    if (!FWD || (P.dbg & 16)) {
+        store_grads();
+        return;
     }
-
-    if (!FWD) return;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const float v = wave_sum(acc[i]);
+        const float v = (P.dbg & 32) ? acc[i] : wave_sum(acc[i]);
         if (lane == 0) red[wave][i] = v;
     }
+    if (P.dbg & 64) {
+        store_grads();
+        return;
+    }
     __syncthreads();
-    if (tid < NPART) {
+    if (wave != 0) {
+        store_grads();
+        return;
+    }
+    if (lane < NPART) {
         float v = 0.f;
-        if (tid < 7) v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        publish(P.partials + (size_t)bid * NPART + tid, v);
+        if (lane < 7) v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (P.fold) publish(P.partials + (size_t)bid * NPART + lane, v);
+        else P.partials[(size_t)bid * NPART + lane] = v;     // read by the next kernel
     }
-    // ---- folded reduction: last workgroup of the group, last group overall
+    if (!P.fold) {      // large grids: no arrival round trip per workgroup
+        store_grads();
+        return;
+    }
     const int grp = k * P.N + n;
-    if (tid == 0) s_flag = arrive(P.counter + grp, P.strict_fences) == S.tiles_per_sample - 1;
-    __syncthreads();
-    if (!s_flag) return;
-    const double gsum = group_sum(P, k, n, s_dbl);
-    if (tid < 7) {
-        publish(P.group + (size_t)grp * NGROUP + tid, gsum);
-        if (tid == 6) P.oob[grp] = (int)gsum;
+    int old = 0;
+    if (lane == 0) old = arrive(P.counter + grp, P.strict_fences);   // waits for the publish only
+    store_grads();
+    if (__shfl(old, 0, kWave) != S.tiles_per_sample - 1) return;
+    const double gsum = group_sum(P, k, n);
+    if (lane < 7) {
+        publish(P.group + (size_t)grp * NGROUP + lane, gsum);
+        if (lane == 6) P.oob[grp] = (int)gsum;
     }
-    __syncthreads();
-    if (tid == 0) s_flag = arrive(P.counter + P.K * P.N, P.strict_fences) == P.K * P.N - 1;
-    __syncthreads();
-    if (!s_flag) return;
-    final_terms(P, s_sum);
+    old = 0;
+    if (lane == 0) old = arrive(P.counter + P.K * P.N, P.strict_fences);
+    if (__shfl(old, 0, kWave) != P.K * P.N - 1) return;
+    final_terms(P);
+}
+
+// The reduction as a launch of its own, one wave per (scale, sample) group,
+// for large grids: there the arrival protocol folded into the sweep costs more
+// than a launch (every workgroup's wave 0 stays resident for a store
+// acknowledgement plus an atomic round trip, and a CU cannot start the next
+// workgroup while its SIMD-0 slots are held: 30 of 136 us at batch 64), here
+// only K*N waves pay it.  Same sums in the same order as the folded form.
+__global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P)
+{
+    const int grp = blockIdx.x, k = grp / P.N, n = grp - k * P.N;
+    const int lane = threadIdx.x;
+    const double gsum = group_sum(P, k, n);
+    if (lane < 7) {
+        publish(P.group + (size_t)grp * NGROUP + lane, gsum);
+        if (lane == 6) P.oob[grp] = (int)gsum;
+    }
+    int old = 0;
+    if (lane == 0) old = arrive(P.counter + P.K * P.N, P.strict_fences);
+    if (__shfl(old, 0, kWave) != P.K * P.N - 1) return;
+    final_terms(P);
 }
 
 // Per-tile out-of-border pixel counts (utils/loss.py:101) ahead of the fused
@@ -717,6 +763,12 @@ void bind_ws(Params &P, void *ws, int nb, float *terms, float *loss_out, const f
     // reduction needs with write-through atomic stores instead.
     static const bool strict = getenv("DVSOF_LOSS_STRICT") != nullptr;
     P.strict_fences = strict ? 1 : 0;
+    static const int dbg = getenv("DVSOF_LOSS_DBG") ? atoi(getenv("DVSOF_LOSS_DBG")) : 0;
+    P.dbg = dbg;
+    // fold the reduction into the sweep while one round of resident workgroups
+    // covers the grid (latency regime); a reduce launch of its own above that
+    static const int fold_max = getenv("DVSOF_LOSS_FOLD_MAX") ? atoi(getenv("DVSOF_LOSS_FOLD_MAX")) : 1536;
+    P.fold = nb <= fold_max ? 1 : 0;
 }
 
 // Pyramid plan: fused single launch when the level sizes are non-decreasing
@@ -805,7 +857,7 @@ extern "C" {
 
 size_t dvsof_loss_workspace_bytes(const dvsof_loss_scale_t *sc, int K, int N)
 {
-    Params P;
+    Params P = {};
     int nb = 0;
     if (build_params(sc, K, N, P, nb) != DVSOF_OK) return 0;
     size_t g, c;
@@ -831,7 +883,7 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
                    const int32_t *stop, float *terms, int32_t *oob, void *ws, size_t ws_bytes,
                    void *stream)
 {
-    Params P;
+    Params P = {};
     int nb = 0;
     const int rc = build_params(sc, K, N, P, nb);
     if (rc) return rc;
@@ -850,13 +902,17 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     DVSOF_LAUNCH_CHECK();
     hipLaunchKernelGGL((loss_main_kernel<true, false>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
     DVSOF_LAUNCH_CHECK();
+    if (!P.fold) {
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(K * N), dim3(kWave), 0, as_stream(stream), P);
+        DVSOF_LAUNCH_CHECK();
+    }
     return DVSOF_OK;
 }
 
 int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *start,
                    const int32_t *stop, const float *seeds, const int32_t *oob, void *stream)
 {
-    Params P;
+    Params P = {};
     int nb = 0;
     const int rc = build_params(sc, K, N, P, nb);
     if (rc) return rc;
@@ -886,7 +942,7 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
                float *terms, float *loss_out, int32_t *oob, void *ws, size_t ws_bytes,
                hipStream_t st)
 {
-    Params P;
+    Params P = {};
     int nb = 0;
     const int rc = build_params(sc, K, N, P, nb);
     if (rc) return rc;
@@ -917,6 +973,10 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
     }
     hipLaunchKernelGGL((loss_main_kernel<true, true>), dim3(nb), dim3(NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
+    if (!P.fold) {
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(K * N), dim3(kWave), 0, st, P);
+        DVSOF_LAUNCH_CHECK();
+    }
     return DVSOF_OK;
 }
 }  // namespace

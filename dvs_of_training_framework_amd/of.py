@@ -90,6 +90,11 @@ class OpticalFlow:
                 g['flow'] = self._net(g['ev'], g['ts'], g['sidx'], self.imsize,
                                       batch_size=B)[0]
             g['graph'] = graph
+            # eager objects the graph's kernels point at (voxeliser workspace,
+            # index vectors) must outlive it whatever their caches do later
+            from . import voxel
+            g['keep'] = (list(voxel._WORKSPACES.values()),
+                         dict(self._net._layout_cache))
         g['graph'].replay()
         if _GRAPH_SYNC:
             g['done'] = torch.cuda.Event()

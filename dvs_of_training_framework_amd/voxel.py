@@ -56,8 +56,8 @@ def _workspace(n, B, C, H, W, device):
             # no warm-up call made one: graph-owned scratch + a memset node
             return (torch.empty(nbytes, dtype=torch.uint8, device=device),
                     nbytes, 0)
-        if len(_WORKSPACES) >= 8:       # a handful of shapes is the normal case
-            _WORKSPACES.clear()
+        if len(_WORKSPACES) >= 16:      # a handful of shapes is the normal case:
+            _WORKSPACES.pop(next(iter(_WORKSPACES)))    # forget the oldest
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         ws[:control].zero_()
         _WORKSPACES[key] = ws

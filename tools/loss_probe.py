@@ -1,0 +1,9 @@
+#!/usr/bin/env python3
+"""Fused loss timing at one shape (probe runs: DVSOF_LOSS_DBG bits).  Prints us per call."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from tools.hbm_bench import loss_case  # noqa: E402
+B, H, W = (int(v) for v in sys.argv[1:4])
+us, alg = loss_case(B, H, W)
+print(f'{us:.1f} us  {alg / us / 1e3:.0f} GB/s')
