@@ -217,6 +217,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int bid = blockIdx.x;
+    if (P.dbg & 128) return;
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -553,15 +554,21 @@ __device__ __forceinline__ void count_oob_block(const Params &P, int bid, int *r
     const float *U = S.flow + (size_t)n * 2 * hw;
     const int x = tx0 + (tid & (TW - 1)), tr = tid >> 6;
     int cnt = 0;
+    // all eight loads first (clamped addresses), then the arithmetic
+    float uu[TH / 4], vv[TH / 4];
+    const int xc = min(x, w - 1);
+#pragma unroll
+    for (int j = 0; j < TH / 4; ++j) {
+        const int o = min(ty0 + tr + 4 * j, h - 1) * w + xc;
+        uu[j] = U[o];
+        vv[j] = U[hw + o];
+    }
 #pragma unroll
     for (int j = 0; j < TH / 4; ++j) {
         const int y = ty0 + tr + 4 * j;
-        if (y < h && x < w) {
-            const size_t o = (size_t)y * w + x;
-            float gx, gy;
-            warp_grid(S, x, y, U[o], U[hw + o], gx, gy);
-            cnt += out_of_border(gx, gy) ? 1 : 0;
-        }
+        float gx, gy;
+        warp_grid(S, x, y, uu[j], vv[j], gx, gy);
+        cnt += ((y < h) & (x < w) & out_of_border(gx, gy)) ? 1 : 0;
     }
     cnt = wave_sum(cnt);
     if ((tid & (kWave - 1)) == 0) red[tid >> 6] = cnt;
@@ -611,9 +618,10 @@ __global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, con
     __shared__ float buf[2][PYR_MAXR];
     __shared__ int red[NT / kWave];
     if ((int)blockIdx.x >= Q.nblocks) {
-        if (do_count) count_oob_block(P, blockIdx.x - Q.nblocks, red);
+        if (do_count && !(P.dbg & 256)) count_oob_block(P, blockIdx.x - Q.nblocks, red);
         return;
     }
+    if (P.dbg & 512) return;
     const int tid = threadIdx.x, K = Q.K;
     const int d = blockIdx.x / Q.tiles_per_frame;
     const int t = blockIdx.x - d * Q.tiles_per_frame;
