@@ -23,11 +23,13 @@
 // registers (same column), a lane shuffle (column to the left) or a 12-entry
 // LDS row per wave (left tile edge): 19 evaluations per channel and 4-pixel
 // strip instead of 36.
-// Reduction: a workgroup writes ONE partial record; the LAST workgroup of a
-// (scale, sample) group to arrive adds that group's records in a fixed order,
-// the LAST group to finish combines the groups, applies the reference's
-// normalisers and writes the terms -- bitwise reproducible (who is last does
-// not change any order of additions), no float atomics, no finalize launch.
+// Reduction: a workgroup adds its 7 sums into its (scale, sample) group's
+// 64-bit FIXED-POINT accumulators (2^-20; integer atomics, no return: the
+// wave does not wait for them) -- integer addition commutes, so the group
+// totals are bitwise reproducible whatever the arrival order.  Small grids:
+// the last workgroup to arrive (one counter) combines the groups, applies the
+// reference's normalisers and writes the terms; large grids: a one-wave
+// reduce launch does (no arrival round trip per workgroup).
 #include "common.h"
 #include <stdlib.h>
 
@@ -54,11 +56,10 @@ struct Params {
     ScaleDev s[DVSOF_MAX_SCALES];
     int K, N;
     const int32_t *start, *stop;
-    float *partials;            // [nb][NPART] per-workgroup sums
     int32_t *oob;               // [K*N] out-of-border pixels per (scale, sample)
     int32_t *oob_tile;          // [nb] the same per tile (launch A) or null: use oob
-    double *group;              // [K*N][NGROUP] group records
-    int *counter;               // [K*N + 1] arrivals per group, finished groups
+    unsigned long long *gacc;   // [K*N][NGROUP] group sums, 2^-20 fixed point (two's complement)
+    int *counter;               // [1] workgroups that have added their sums
     const float *seeds_dev;     // [3*K] or null
     float seeds_host[3];        // used when seeds_dev == null
     float *terms, *loss_out;    // outputs of the folded reduction
@@ -102,23 +103,22 @@ __device__ __forceinline__ bool out_of_border(float gx, float gy)
     return (gx < -1.f) | (gx > 1.f) | (gy < -1.f) | (gy > 1.f);
 }
 
-constexpr int NGROUP = 8;   // doubles per group record: 7 sums + pad
+constexpr int NGROUP = 8;   // accumulators per group: 7 sums + pad
 constexpr int NW = NT / kWave;
+constexpr float FIX_SCALE = 1048576.f;              // 2^20
+constexpr double FIX_INV = 1.0 / 1048576.0;
 
-// Publish / observe protocol of the folded reduction.  Everything one
-// workgroup hands to another goes through agent-scope ATOMIC accesses only:
-// records are written with agent-scope atomic stores (the backend emits them
-// write-through, sc1: they do not linger in this XCD's non-coherent L2) and
-// read with agent-scope atomic loads; the arrival counters are agent-scope
-// RMWs.  Ordering: the publishing wave waits until its stores are acknowledged
-// (s_waitcnt vmcnt(0)) before it bumps the counter -- the agent-scope release
-// sequence of the LLVM AMDGPU memory model for gfx942/gfx950 is exactly
-// {buffer_wbl2 sc1; s_waitcnt vmcnt(0)}, and the wbl2 only exists to write
-// back NON-atomic dirty lines, of which this protocol publishes none.  The
-// reader's loads are atomic too, so no acquire-side invalidate is needed.
-// With strict_fences (DVSOF_LOSS_STRICT=1) the RMW is bracketed by the
+// Publish / observe protocol of the folded reduction.  What one workgroup
+// hands to another goes through agent-scope ATOMIC accesses only: the sums
+// are agent-scope integer RMWs on the group accumulators, read back with
+// agent-scope atomic loads; the arrival counter is an agent-scope RMW issued
+// after the wave's accumulator atomics have been acknowledged
+// (s_waitcnt vmcnt(0)).  That is the agent-scope release sequence of the LLVM
+// AMDGPU memory model for gfx942/gfx950 minus its buffer_wbl2, which only
+// writes back NON-atomic dirty lines -- none are published here.  With
+// strict_fences (DVSOF_LOSS_STRICT=1) the counter RMW is bracketed by the
 // model's full agent-scope release / acquire fences instead; same results
-// (tests run both), 2.3x the kernel time (bind_ws).
+// (tests run both), at a cost (bind_ws).
 __device__ __forceinline__ int arrive(int *counter, int strict)
 {
     if (strict) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -127,65 +127,72 @@ __device__ __forceinline__ int arrive(int *counter, int strict)
     if (strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return old;
 }
-__device__ __forceinline__ void publish(double *p, double v)
+__device__ __forceinline__ void accumulate(unsigned long long *p, float v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // v >= 0 here (sums of rho values, counts); two's complement keeps the door open
+    const long long q = (long long)__builtin_rintf(v * FIX_SCALE);
+    __hip_atomic_fetch_add(p, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void publish(float *p, float v)
+template <bool COHERENT>
+__device__ __forceinline__ double group_value(const unsigned long long *p)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ T observe(const T *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Group (k, n): add its tile records in a fixed order (double).  ONE wave
-// (the closing workgroup's wave 0: the other waves have retired); lane i < 7
-// returns sum i.
-__device__ __forceinline__ double group_sum(const Params &P, int k, int n)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const ScaleDev &S = P.s[k];
-    const float *part = P.partials + ((size_t)S.block_begin + (size_t)n * S.tiles_per_sample) * NPART;
-    double a[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int b = lane; b < S.tiles_per_sample; b += kWave) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) a[i] += (double)observe(part + (size_t)b * NPART + i);
-    }
-    double mine = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const double v = __shfl(wave_sum(a[i]), 0, kWave);
-        if (lane == i) mine = v;
-    }
-    return mine;
+    const unsigned long long u = COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : *p;
+    return (double)(long long)u * FIX_INV;
 }
 
-// Last group: items (k, i), i < 5: global sums of photo + the four smoothness
-// directions; i == 5: border term = sum_n bs_n / (2 c_n N) (utils/loss.py:101,113).
-// One wave; lane 0 ends up with every item and writes the terms.
+// Every group is complete.  One wave combines them: a group's 8 accumulators
+// are 64 contiguous bytes, so lane l reads element l % 8 of sample 8 j + l / 8
+// (8 samples per load instruction, the loads of ALL scales and of 2 sample
+// blocks in flight together: the chain of memory round trips is N / 16 long,
+// not N), lanes of equal l % 8 add their samples in j order, and the eight
+// lane groups meet by three shuffle steps.  Elements 0..4: sums over the
+// samples of photo + the four smoothness directions; element 5: border term
+// = sum_n bs_n / (2 c_n N) with c_n = element 6 of the same sample
+// (utils/loss.py:101,113).
+// COHERENT: the accumulators were updated by other workgroups of the SAME
+// launch (agent-scope loads); otherwise by an earlier launch (plain loads).
+template <bool COHERENT>
 __device__ __forceinline__ void final_terms(const Params &P)
 {
-    const int lane = threadIdx.x & (kWave - 1);
+    const int lane = threadIdx.x & (kWave - 1), e = lane & 7, g = lane >> 3;
+    double acc[DVSOF_MAX_SCALES];
+#pragma unroll
+    for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) acc[kk] = 0;
+    for (int n0 = 0; n0 < P.N; n0 += 16) {
+        double x[DVSOF_MAX_SCALES][2];
+#pragma unroll
+        for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int nn = min(n0 + 8 * u + g, P.N - 1);
+                x[kk][u] = kk < P.K ? group_value<COHERENT>(P.gacc + ((size_t)kk * P.N + nn) * NGROUP + e) : 0.0;
+            }
+#pragma unroll
+        for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) {
+            if (kk >= P.K) break;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int nn = n0 + 8 * u + g;
+                const double c = __shfl(x[kk][u], (lane & ~7) | 6, kWave);    // the sample's count
+                if (nn >= P.N) continue;
+                if (e < 5) acc[kk] += x[kk][u];
+                else if (e == 5 && c > 0) acc[kk] += x[kk][u] / (2.0 * c * (double)P.N);
+                else if (e == 6) P.oob[kk * P.N + nn] = (int)c;    // kept for dvsof_loss_bwd
+            }
+        }
+    }
     double total[3] = {0, 0, 0};
-    for (int kk = 0; kk < P.K; ++kk) {
+#pragma unroll
+    for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) {
+        if (kk >= P.K) break;
+        double a = acc[kk];
+        a += __shfl_xor(a, 8, kWave);
+        a += __shfl_xor(a, 16, kWave);
+        a += __shfl_xor(a, 32, kWave);
         double a6[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double a = 0;
-            for (int nn = lane; nn < P.N; nn += kWave) {
-                const double *g = P.group + ((size_t)kk * P.N + nn) * NGROUP;
-                if (i < 5) {
-                    a += observe(g + i);
-                } else {
-                    const double bs = observe(g + 5), c = observe(g + 6);
-                    if (c > 0) a += bs / (2.0 * c * (double)P.N);
-                }
-            }
-            a6[i] = wave_sum(a);
-        }
+        for (int j = 0; j < 6; ++j) a6[j] = __shfl(a, j, kWave);
         if (lane == 0) {
             const ScaleDev &S = P.s[kk];
             // empty crops contribute 0 (utils/loss.py:29-30)
@@ -455,11 +462,9 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
         }
     }
     // ---- tail.  Waves 1..3 store their gradients and RETIRE; wave 0 alone
-    // publishes the workgroup's sums, bumps the arrival counter, stores its
-    // own gradients while that atomic is in flight, and -- if it was the last
-    // of its group / the last group -- reduces with its 64 lanes.  (With the
-    // whole workgroup waiting for wave 0's atomic, every workgroup held its
-    // four wave slots for a memory round trip longer: 30 of 136 us at batch 64.)
+    // adds the workgroup's sums to its group's accumulators and, on small
+    // grids, bumps the arrival counter, stores its own gradients while that
+    // atomic is in flight, and combines everything if it was the last.
     auto store_grads = [&]() {
         if (!BWD || (P.dbg & 8)) return;
 #pragma unroll
@@ -488,52 +493,26 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
         store_grads();
         return;
     }
-    if (lane < NPART) {
-        float v = 0.f;
-        if (lane < 7) v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (P.fold) publish(P.partials + (size_t)bid * NPART + lane, v);
-        else P.partials[(size_t)bid * NPART + lane] = v;     // read by the next kernel
-    }
-    if (!P.fold) {      // large grids: no arrival round trip per workgroup
+    const int grp = k * P.N + n;
+    if (lane < 7)
+        accumulate(P.gacc + (size_t)grp * NGROUP + lane,
+                   (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    if (!P.fold) {      // large grids: the wave does not wait for anything
         store_grads();
         return;
     }
-    const int grp = k * P.N + n;
     int old = 0;
-    if (lane == 0) old = arrive(P.counter + grp, P.strict_fences);   // waits for the publish only
+    if (lane == 0) old = arrive(P.counter, P.strict_fences);   // waits for the accumulator atomics only
     store_grads();
-    if (__shfl(old, 0, kWave) != S.tiles_per_sample - 1) return;
-    const double gsum = group_sum(P, k, n);
-    if (lane < 7) {
-        publish(P.group + (size_t)grp * NGROUP + lane, gsum);
-        if (lane == 6) P.oob[grp] = (int)gsum;
-    }
-    old = 0;
-    if (lane == 0) old = arrive(P.counter + P.K * P.N, P.strict_fences);
-    if (__shfl(old, 0, kWave) != P.K * P.N - 1) return;
-    final_terms(P);
+    if (__shfl(old, 0, kWave) != (int)gridDim.x - 1) return;
+    final_terms<true>(P);
 }
 
-// The reduction as a launch of its own, one wave per (scale, sample) group,
-// for large grids: there the arrival protocol folded into the sweep costs more
-// than a launch (every workgroup's wave 0 stays resident for a store
-// acknowledgement plus an atomic round trip, and a CU cannot start the next
-// workgroup while its SIMD-0 slots are held: 30 of 136 us at batch 64), here
-// only K*N waves pay it.  Same sums in the same order as the folded form.
-__global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P)
-{
-    const int grp = blockIdx.x, k = grp / P.N, n = grp - k * P.N;
-    const int lane = threadIdx.x;
-    const double gsum = group_sum(P, k, n);
-    if (lane < 7) {
-        publish(P.group + (size_t)grp * NGROUP + lane, gsum);
-        if (lane == 6) P.oob[grp] = (int)gsum;
-    }
-    int old = 0;
-    if (lane == 0) old = arrive(P.counter + P.K * P.N, P.strict_fences);
-    if (__shfl(old, 0, kWave) != P.K * P.N - 1) return;
-    final_terms(P);
-}
+// The final combination as a launch of its own (one wave) for large grids:
+// there an arrival round trip per workgroup costs more than a launch (a CU
+// cannot start the next workgroup while its SIMD-0 slots are held by waves
+// waiting for their atomic's return).
+__global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P) { final_terms<false>(P); }
 
 // Per-tile out-of-border pixel counts (utils/loss.py:101) ahead of the fused
 // forward+backward sweep: plain stores, one int per tile.  Workgroup 0 also
@@ -541,8 +520,10 @@ __global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P)
 __device__ __forceinline__ void count_oob_block(const Params &P, int bid, int *red)
 {
     const int tid = threadIdx.x;
-    if (bid == 0 && P.counter)
-        for (int i = tid; i <= P.K * P.N; i += NT) P.counter[i] = 0;
+    if (bid == 0 && P.counter) {     // accumulators and arrival counter of the sweep that follows
+        for (int i = tid; i < P.K * P.N * NGROUP; i += NT) P.gacc[i] = 0ull;
+        if (tid == 0) P.counter[0] = 0;
+    }
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -736,45 +717,40 @@ int build_params(const dvsof_loss_scale_t *sc, int K, int N, Params &P, int &tot
     return DVSOF_OK;
 }
 
-// workspace: [partials nb*NPART f32][group K*N*NGROUP f64][oob_tile nb i32]
-//            [counters (K*N + 1) i32]
-size_t ws_layout(int nb, int K, int N, size_t &group_off, size_t &counter_off)
+// workspace: [gacc K*N*NGROUP u64][oob_tile nb i32][counter i32]
+size_t ws_layout(int nb, int K, int N, size_t &tile_off, size_t &counter_off)
 {
-    size_t o = (size_t)nb * NPART * sizeof(float);
-    o = (o + 15) & ~(size_t)15;
-    group_off = o;
-    o += (size_t)K * N * NGROUP * sizeof(double);
+    size_t o = (size_t)K * N * NGROUP * sizeof(unsigned long long);
+    tile_off = o;
     o += (size_t)nb * sizeof(int32_t);
     o = (o + 15) & ~(size_t)15;
     counter_off = o;
-    return o + ((size_t)K * N + 1) * sizeof(int) + 16;
+    return o + 16;
 }
 
 void bind_ws(Params &P, void *ws, int nb, float *terms, float *loss_out, const float *w,
              float loss_scale)
 {
-    size_t g, c;
-    ws_layout(nb, P.K, P.N, g, c);
-    P.partials = (float *)ws;
-    P.group = (double *)((char *)ws + g);
-    P.oob_tile = (int32_t *)((char *)ws + g + (size_t)P.K * P.N * NGROUP * sizeof(double));
+    size_t t, c;
+    ws_layout(nb, P.K, P.N, t, c);
+    P.gacc = (unsigned long long *)ws;
+    P.oob_tile = (int32_t *)((char *)ws + t);
     P.counter = (int *)((char *)ws + c);
     P.terms = terms;
     P.loss_out = loss_out;
     for (int i = 0; i < 3; ++i) P.wts[i] = w ? w[i] : 0.f;
     P.loss_scale = loss_scale;
-    // DVSOF_LOSS_STRICT=1: additionally bracket the arrival counters with the
+    // DVSOF_LOSS_STRICT=1: additionally bracket the arrival counter with the
     // memory model's agent-scope release / acquire fences (see arrive()).
-    // Measured on MI355X: the release fence in EVERY workgroup (buffer_wbl2 of
-    // an L2 full of freshly written gradients) takes the fused loss from
-    // 126 to 291 us at batch 64 -- so the default publishes the few words the
-    // reduction needs with write-through atomic stores instead.
+    // Measured on MI355X (round-2 stage a): the release fence in EVERY
+    // workgroup (buffer_wbl2 of an L2 full of freshly written gradients) took
+    // the fused loss from 126 to 291 us at batch 64.
     static const bool strict = getenv("DVSOF_LOSS_STRICT") != nullptr;
     P.strict_fences = strict ? 1 : 0;
     static const int dbg = getenv("DVSOF_LOSS_DBG") ? atoi(getenv("DVSOF_LOSS_DBG")) : 0;
     P.dbg = dbg;
-    // fold the reduction into the sweep while one round of resident workgroups
-    // covers the grid (latency regime); a reduce launch of its own above that
+    // the last-arriving workgroup combines while one round of resident
+    // workgroups covers the grid (latency regime); a reduce launch above that
     static const int fold_max = getenv("DVSOF_LOSS_FOLD_MAX") ? atoi(getenv("DVSOF_LOSS_FOLD_MAX")) : 1536;
     P.fold = nb <= fold_max ? 1 : 0;
 }
@@ -911,7 +887,7 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     hipLaunchKernelGGL((loss_main_kernel<true, false>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
     DVSOF_LAUNCH_CHECK();
     if (!P.fold) {
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(K * N), dim3(kWave), 0, as_stream(stream), P);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, as_stream(stream), P);
         DVSOF_LAUNCH_CHECK();
     }
     return DVSOF_OK;
@@ -929,8 +905,7 @@ int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
         if (!sc[k].grad_flow) return DVSOF_EINVAL;
     P.start = start;
     P.stop = stop;
-    P.partials = nullptr;
-    P.group = nullptr;
+    P.gacc = nullptr;
     P.counter = nullptr;
     P.oob_tile = nullptr;       // totals of the forward call
     P.terms = P.loss_out = nullptr;
@@ -982,7 +957,7 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
     hipLaunchKernelGGL((loss_main_kernel<true, true>), dim3(nb), dim3(NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
     if (!P.fold) {
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(K * N), dim3(kWave), 0, st, P);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, st, P);
         DVSOF_LAUNCH_CHECK();
     }
     return DVSOF_OK;
