@@ -139,7 +139,7 @@ constexpr int VPX_MAX = 1024;
 constexpr int64_t EPT8_FROM = 1 << 21;
 // 16 from ~4 M events: half the bucket-cursor atomics, twice as long record runs per tile
 constexpr int64_t EPT16_FROM = 3 << 20;
-constexpr int V2_MAX_TILES = 8192;
+constexpr int V2_MAX_TILES = 8192;    // LDS histogram + base of the bucket pass: 8 bytes per tile (64 KiB)
 
 struct VoxV2 {
     // wire format (int64 columns) ...
@@ -371,10 +371,21 @@ bool v2_plan(int64_t n, int B, int C, int H, int W, VoxV2 &P)
     // fewer than three workgroups per CU (160 KiB LDS)
     const int lp = (size_t)C * 1024 * 8 > 52 * 1024 ? 9 : 10;
     P.lp = lp;
-    // tile width: the frame's width rounded up to a power of two, 64..2^lp
+    // tile width 2^lx, 64 <= 2^lx <= 2^lp: the widest one whose column padding
+    // (TX * 2^lx - W) stays within an eighth of the frame, else the one with
+    // the least padding (640 -> 128, 346 -> 128, 256 -> 256, 512 -> 512)
     static const int lx_env = getenv("DVSOF_VOX_TILE_LOG2X") ? atoi(getenv("DVSOF_VOX_TILE_LOG2X")) : 0;
-    int lx = 6;
-    while (lx < lp && (1 << lx) < W) ++lx;
+    int lx = 6, best_pad = 1 << 30;
+    for (int c = 6; c <= lp; ++c) {
+        const int wd = 1 << c, padded = (W + wd - 1) / wd * wd;
+        if (padded * 8 <= W * 9) {
+            lx = c;             // within 12.5 %: wider is better
+            best_pad = 0;
+        } else if (best_pad && padded - W < best_pad) {
+            best_pad = padded - W;
+            lx = c;
+        }
+    }
     if (lx_env >= 2 && lx_env <= lp) lx = lx_env;
     P.lx = lx;
     const int vtx = 1 << lx, vty = 1 << (lp - lx);
