@@ -129,6 +129,11 @@ def add_train_arguments(parser):           # utils/options.py:204-302
                         help='matrix-core operand type of the conv stack: exact f32, '
                              'bf16 hi+lo split (three products, ~f32 accuracy) or bf16; '
                              'storage and accumulation are f32 in every mode')
+    parser.add_argument('--capture', action='store_true',
+                        help='replay the loop body as one hipGraph launch per '
+                             'step once a batch signature has been seen '
+                             '(capture.CapturedTrainStep; ADAM, single process, '
+                             'no gradient accumulation)')
     parser.add_argument('--compact-events', dest='compact_events',
                         action='store_true',
                         help='with --preprocessed-dataset-path: hand raw '

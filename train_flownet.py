@@ -208,7 +208,8 @@ def main(argv=None):
           scheduler=scheduler, evaluator=losses, logger=logger,
           weights=args.loss_weights, is_raw=args.is_raw,
           accumulation_steps=args.accum_step, timers=timers, hooks={},
-          max_events_per_batch=args.max_events_per_batch, reducer=reducer)
+          max_events_per_batch=args.max_events_per_batch, reducer=reducer,
+          capture=getattr(args, 'capture', False))
     if rank == 0:
         torch.save({'model': model.state_dict(),
                     'optimizer': optimizer.state_dict(),
