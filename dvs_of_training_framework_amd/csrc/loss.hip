@@ -6,12 +6,13 @@
 // :92-119 (out-of-border), :121-171 (Loss.__call__), and the autograd
 // backward that utils/training.py:158 runs through them.
 //
-// HBM-bound kernels, two launches per evaluation:
+// HBM-bound kernels, three launches per evaluation (A, B and the one-wave C):
 //   A  loss_pyramid_kernel: the cascaded frame pyramid; its tail workgroups
 //      count out-of-border pixels per tile (plain stores, no atomics, nothing
-//      to zero) and workgroup 0 clears the arrival counters of launch B;
+//      to zero) and workgroup 0 clears the group accumulators of launch B;
 //   B  loss_main_kernel: all scales, forward sums and flow gradients in one
-//      sweep, and the reduction of the sums folded in (below).
+//      sweep;
+//   C  loss_reduce_kernel: one wave combines the per-group sums.
 // Layout: flow [N,2,h,w] and frames [D,h,w] row-major.  A 256-thread
 // workgroup owns a 64x16 pixel tile of one sample at one scale: wave v owns
 // rows 4v..4v+3, lane l column l, so a thread holds a 4-pixel column strip.
@@ -26,10 +27,10 @@
 // Reduction: a workgroup adds its 7 sums into its (scale, sample) group's
 // 64-bit FIXED-POINT accumulators (2^-20; integer atomics, no return: the
 // wave does not wait for them) -- integer addition commutes, so the group
-// totals are bitwise reproducible whatever the arrival order.  Small grids:
-// the last workgroup to arrive (one counter) combines the groups, applies the
-// reference's normalisers and writes the terms; large grids: a one-wave
-// reduce launch does (no arrival round trip per workgroup).
+// totals are bitwise reproducible whatever the arrival order.  A one-wave
+// launch (C) then combines the groups, applies the reference's normalisers
+// and writes the terms: the kernel boundary orders it behind the atomics, so
+// there is no in-kernel publish / observe protocol at all.
 #include "common.h"
 #include <stdlib.h>
 
@@ -59,14 +60,11 @@ struct Params {
     int32_t *oob;               // [K*N] out-of-border pixels per (scale, sample)
     int32_t *oob_tile;          // [nb] the same per tile (launch A) or null: use oob
     unsigned long long *gacc;   // [K*N][NGROUP] group sums, 2^-20 fixed point (two's complement)
-    int *counter;               // [1] workgroups that have added their sums
     const float *seeds_dev;     // [3*K] or null
     float seeds_host[3];        // used when seeds_dev == null
-    float *terms, *loss_out;    // outputs of the folded reduction
+    float *terms, *loss_out;    // outputs of loss_reduce_kernel
     float wts[3], loss_scale;
-    int strict_fences;          // agent-scope release/acquire fences around the counters
     int dbg;                    // DVSOF_LOSS_DBG timing probes (results wrong by construction)
-    int fold;                   // 1: the sweep's last-arriving workgroups reduce; 0: loss_reduce_kernel does
 };
 
 __device__ __forceinline__ int find_scale(const Params &P, int bid)
@@ -108,37 +106,17 @@ constexpr int NW = NT / kWave;
 constexpr float FIX_SCALE = 1048576.f;              // 2^20
 constexpr double FIX_INV = 1.0 / 1048576.0;
 
-// Publish / observe protocol of the folded reduction.  What one workgroup
-// hands to another goes through agent-scope ATOMIC accesses only: the sums
-// are agent-scope integer RMWs on the group accumulators, read back with
-// agent-scope atomic loads; the arrival counter is an agent-scope RMW issued
-// after the wave's accumulator atomics have been acknowledged
-// (s_waitcnt vmcnt(0)).  That is the agent-scope release sequence of the LLVM
-// AMDGPU memory model for gfx942/gfx950 minus its buffer_wbl2, which only
-// writes back NON-atomic dirty lines -- none are published here.  With
-// strict_fences (DVSOF_LOSS_STRICT=1) the counter RMW is bracketed by the
-// model's full agent-scope release / acquire fences instead; same results
-// (tests run both), at a cost (bind_ws).
-__device__ __forceinline__ int arrive(int *counter, int strict)
-{
-    if (strict) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return old;
-}
+// A workgroup's sum into its group's accumulator: agent-scope integer RMW, no
+// return (the wave does not wait for it).  The reader is the next launch.
 __device__ __forceinline__ void accumulate(unsigned long long *p, float v)
 {
     // v >= 0 here (sums of rho values, counts); two's complement keeps the door open
     const long long q = (long long)__builtin_rintf(v * FIX_SCALE);
     __hip_atomic_fetch_add(p, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <bool COHERENT>
 __device__ __forceinline__ double group_value(const unsigned long long *p)
 {
-    const unsigned long long u = COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                          : *p;
-    return (double)(long long)u * FIX_INV;
+    return (double)(long long)*p * FIX_INV;
 }
 
 // Every group is complete.  One wave combines them: a group's 8 accumulators
@@ -150,29 +128,27 @@ __device__ __forceinline__ double group_value(const unsigned long long *p)
 // samples of photo + the four smoothness directions; element 5: border term
 // = sum_n bs_n / (2 c_n N) with c_n = element 6 of the same sample
 // (utils/loss.py:101,113).
-// COHERENT: the accumulators were updated by other workgroups of the SAME
-// launch (agent-scope loads); otherwise by an earlier launch (plain loads).
-template <bool COHERENT>
 __device__ __forceinline__ void final_terms(const Params &P)
 {
     const int lane = threadIdx.x & (kWave - 1), e = lane & 7, g = lane >> 3;
     double acc[DVSOF_MAX_SCALES];
 #pragma unroll
     for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) acc[kk] = 0;
-    for (int n0 = 0; n0 < P.N; n0 += 16) {
-        double x[DVSOF_MAX_SCALES][2];
+    constexpr int UB = 4;       // sample blocks of 8 per pass: K * UB loads in flight per lane
+    for (int n0 = 0; n0 < P.N; n0 += 8 * UB) {
+        double x[DVSOF_MAX_SCALES][UB];
 #pragma unroll
         for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 const int nn = min(n0 + 8 * u + g, P.N - 1);
-                x[kk][u] = kk < P.K ? group_value<COHERENT>(P.gacc + ((size_t)kk * P.N + nn) * NGROUP + e) : 0.0;
+                x[kk][u] = kk < P.K ? group_value(P.gacc + ((size_t)kk * P.N + nn) * NGROUP + e) : 0.0;
             }
 #pragma unroll
         for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) {
             if (kk >= P.K) break;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 const int nn = n0 + 8 * u + g;
                 const double c = __shfl(x[kk][u], (lane & ~7) | 6, kWave);    // the sample's count
                 if (nn >= P.N) continue;
@@ -218,7 +194,6 @@ template <bool FWD, bool BWD>
 __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 {
     __shared__ float sF[2][LH][LW];
-    __shared__ float sE[NW][2][12];      // left-edge column derivatives, per wave
     __shared__ float red[NW][NPART];
     __shared__ int s_cnt[NW];
 
@@ -292,70 +267,64 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     constexpr int NP = 4;                // pixels per thread: rows ly0 .. ly0 + 3
     // phase A: addresses and ALL gathers of the thread's pixels first, so the
     // 5*NP loads are in flight together instead of NP dependent round trips
+    // Taps outside the frame read as zero (grid_sample's zero padding) through
+    // the buffer range check: an invalid tap gets an offset past the frame's
+    // byte count, so there are no clamps, no validity factors to keep in
+    // registers, no exec-mask branches -- and all 20 loads are in flight.
     bool valid[NP], oobv[NP];
-    float uu[NP], vv[NP], axv[NP], ayv[NP], nwv[NP], nev[NP], swv[NP], sev[NP], prv[NP];
-    float m00[NP], m01[NP], m10[NP], m11[NP];
-    const int xc = min(x, w - 1);
+    float axv[NP], ayv[NP], nwv[NP], nev[NP], swv[NP], sev[NP], prv[NP];
+    {
+        const __amdgpu_buffer_rsrc_t r1 =
+            __builtin_amdgcn_make_buffer_rsrc((void *)I1, 0, (int)(hw * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r0 =
+            __builtin_amdgcn_make_buffer_rsrc((void *)I0, 0, (int)(hw * 4), 0x00020000);
+        constexpr unsigned OOB = 0xffffffffu;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int ly = ly0 + j, y = ty0 + ly;
-        valid[j] = (y < h) & (x < w);
-        const float u = sF[0][ly + 1][lane + 1], v = sF[1][ly + 1][lane + 1];
-        uu[j] = u;
-        vv[j] = v;
-        float gx, gy;
-        warp_grid(S, x, y, u, v, gx, gy);
-        oobv[j] = out_of_border(gx, gy);
-        // grid_sample(bilinear, zeros, align_corners=True): utils/loss.py:70
-        const float ix = (gx + 1.f) * S.half_w, iy = (gy + 1.f) * S.half_h;
-        const float fx0 = floorf(ix), fy0 = floorf(iy);
-        axv[j] = ix - fx0;
-        ayv[j] = iy - fy0;
-        const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f);
-        const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
-        // unconditional loads from clamped addresses, zero padding as a 0/1
-        // factor afterwards: no exec-mask branch per tap, all loads in flight
-        const float vx0 = ((x0 >= 0) & (x0 < w)) ? 1.f : 0.f, vx1 = ((x0 >= -1) & (x0 + 1 < w)) ? 1.f : 0.f;
-        const float vy0 = ((y0 >= 0) & (y0 < h)) ? 1.f : 0.f, vy1 = ((y0 >= -1) & (y0 + 1 < h)) ? 1.f : 0.f;
-        const float mv = valid[j] ? 1.f : 0.f;
-        m00[j] = mv * vy0 * vx0;
-        m01[j] = mv * vy0 * vx1;
-        m10[j] = mv * vy1 * vx0;
-        m11[j] = mv * vy1 * vx1;
-        const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
-        const int ya = min(max(y0, 0), h - 1) * w, yb = min(max(y0 + 1, 0), h - 1) * w;
-        if (P.dbg & 4) {        // probe: no gathers
-            nwv[j] = nev[j] = swv[j] = sev[j] = prv[j] = u;
-        } else {
-        nwv[j] = I1[ya + xa];
-        nev[j] = I1[ya + xb];
-        swv[j] = I1[yb + xa];
-        sev[j] = I1[yb + xb];
-        prv[j] = I0[min(y, h - 1) * w + xc];
+        for (int j = 0; j < NP; ++j) {
+            const int ly = ly0 + j, y = ty0 + ly;
+            valid[j] = (y < h) & (x < w);
+            const float u = sF[0][ly + 1][lane + 1], v = sF[1][ly + 1][lane + 1];
+            float gx, gy;
+            warp_grid(S, x, y, u, v, gx, gy);
+            oobv[j] = out_of_border(gx, gy);
+            // grid_sample(bilinear, zeros, align_corners=True): utils/loss.py:70
+            const float ix = (gx + 1.f) * S.half_w, iy = (gy + 1.f) * S.half_h;
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            axv[j] = ix - fx0;
+            ayv[j] = iy - fy0;
+            const int x0 = (int)fminf(fmaxf(fx0, -2.f), (float)w + 1.f);
+            const int y0 = (int)fminf(fmaxf(fy0, -2.f), (float)h + 1.f);
+            const bool vx0 = (unsigned)x0 < (unsigned)w, vx1 = (unsigned)(x0 + 1) < (unsigned)w;
+            const bool vy0 = valid[j] & ((unsigned)y0 < (unsigned)h), vy1 = valid[j] & ((unsigned)(y0 + 1) < (unsigned)h);
+            const unsigned o00 = (unsigned)((y0 * w + x0) * 4), o10 = o00 + (unsigned)(w * 4);
+            nwv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (vy0 & vx0) ? o00 : OOB, 0, 0));
+            nev[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (vy0 & vx1) ? o00 + 4 : OOB, 0, 0));
+            swv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (vy1 & vx0) ? o10 : OOB, 0, 0));
+            sev[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (vy1 & vx1) ? o10 + 4 : OOB, 0, 0));
+            prv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                r0, valid[j] ? (unsigned)((y * w + x) * 4) : OOB, 0, 0));
+            if (P.dbg & 4) nwv[j] = nev[j] = swv[j] = sev[j] = prv[j] = u;     // probe: keeps the loads dead
         }
-    }
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        nwv[j] *= m00[j];
-        nev[j] *= m01[j];
-        swv[j] *= m10[j];
-        sev[j] *= m11[j];
     }
 
     // left-edge column (x = tx0 - 1) derivatives the strip's lane 0 needs:
-    // lanes 0..23 of every wave evaluate one each -> sE[wave][channel][kind*4 + r],
-    // kind 0: d0(r, xe), 1: d2(r-1, xe), 2: d3(r, xe)
+    // lane 12 c + 4 kind + r (< 24) of every wave evaluates one -- kind 0:
+    // d0(r, xe), 1: d2(r-1, xe), 2: d3(r, xe) -- and lane 0 picks them up with
+    // v_readlane (no LDS, no barrier).
+    float edge = 0.f;
     if (BWD) {
-        if (lane < 24) {
-            const int c = lane / 12, q = lane - 12 * c, kind = q >> 2, r = q & 3;
-            const int db = kind == 1 ? -1 : (kind == 2 ? 1 : 0);
-            const int ya = ty0 + ly0 + r, yb = ya + db;
-            const bool ok = (tx0 >= 1) & (ya >= 0) & (ya < h) & (yb >= 0) & (yb < h);
-            const float fa = sF[c][ly0 + r + 1][1], fb = sF[c][ly0 + r + 1 + db][0];
-            sE[wave][c][q] = ok ? charbonnier(fa - fb).der : 0.f;
-        }
-        __syncthreads();
+        const int l = lane < 24 ? lane : 0;
+        const int c = l / 12, q = l - 12 * c, kind = q >> 2, r = q & 3;
+        const int db = kind == 1 ? -1 : (kind == 2 ? 1 : 0);
+        const int ya = ty0 + ly0 + r, yb = ya + db;
+        const bool ok = (tx0 >= 1) & (ya >= 0) & (ya < h) & (yb >= 0) & (yb < h);
+        const float fa = sF[c][ly0 + r + 1][1], fb = sF[c][ly0 + r + 1 + db][0];
+        edge = ok ? charbonnier(fa - fb).der : 0.f;
     }
+    const int edge_bits = __builtin_bit_cast(int, edge);
+    auto edge_at = [&](int src) -> float {      // uniform value of lane `src`
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(edge_bits, src));
+    };
 
     float gu[NP], gv[NP];
 #pragma unroll
@@ -375,7 +344,8 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
             gv[j] = gp * ((sw - nw) * cx + (se - ne) * ax);
         }
         if (oobv[j]) {
-            const Charb bu = charbonnier(uu[j]), bv = charbonnier(vv[j]);
+            const Charb bu = charbonnier(sF[0][ly0 + j + 1][lane + 1]),
+                        bv = charbonnier(sF[1][ly0 + j + 1][lane + 1]);
             if (FWD) {
                 acc[5] += bu.val + bv.val;
                 acc[6] += 1.f;
@@ -402,63 +372,66 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
             const int y = ty0 + ly0 + r - 1;
             mrow[r] = ((y >= 0) & (y < h)) ? 1.f : 0.f;
         }
-        f32x2 a0[6], a1[6];                // columns x, x+1; rows -1..4; (u, v)
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            a0[r] = f32x2{sF[0][ly0 + r][lane + 1], sF[1][ly0 + r][lane + 1]};
-            a1[r] = f32x2{sF[0][ly0 + r][lane + 2], sF[1][ly0 + r][lane + 2]};
-        }
-        f32x2 d0[5], d1[5], d2[5], d3[5];  // index r + 1
+        // Rolling window over the anchor rows -1..3: with the anchors of row
+        // r and r - 1 in hand, pixel row r is complete -- only two rows of
+        // derivatives live in registers (all five: 70 VGPRs more, occupancy 3).
         f32x2 s1 = {0.f, 0.f}, s2 = s1, s3 = s1, s4 = s1;
-        d0[0] = s1;
+        f32x2 p0 = {sF[0][ly0][lane + 1], sF[1][ly0][lane + 1]};     // row -1: columns x, x + 1
+        f32x2 p1 = {sF[0][ly0][lane + 2], sF[1][ly0][lane + 2]};
+        f32x2 d1p = s1, d2p = s1, d3p = s1;                           // anchor row r - 1
+        const float k0 = S.k_smooth[0] * seed[0], k1 = S.k_smooth[1] * seed[0],
+                    k2 = S.k_smooth[2] * seed[0];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const bool own = r >= 1;       // anchor row of this strip: sums count
+        for (int r = 0; r < 5; ++r) {          // anchor strip row r - 1
+            const f32x2 n0 = {sF[0][ly0 + r + 1][lane + 1], sF[1][ly0 + r + 1][lane + 1]};
+            const f32x2 n1 = {sF[0][ly0 + r + 1][lane + 2], sF[1][ly0 + r + 1][lane + 2]};
+            const bool own = r >= 1;           // anchor row of this strip: sums count
             const float m0 = mrow[r] * mxr, mv = mrow[r] * mrow[r + 1];
             const float m1 = mv * mx, m2 = mv * mxr;
+            f32x2 d0c = {0.f, 0.f};
             if (own) {
-                const Charb2 q = charbonnier2(a1[r] - a0[r]);
+                const Charb2 q = charbonnier2(p1 - p0);
                 if (FWD) s1 += q.val * m0;
-                d0[r] = q.der * m0;
+                d0c = q.der * m0;
             }
-            const Charb2 q1 = charbonnier2(a0[r + 1] - a0[r]);
-            const Charb2 q2 = charbonnier2(a1[r + 1] - a0[r]);
-            const Charb2 q3 = charbonnier2(a1[r] - a0[r + 1]);
+            const Charb2 q1 = charbonnier2(n0 - p0);
+            const Charb2 q2 = charbonnier2(n1 - p0);
+            const Charb2 q3 = charbonnier2(p1 - n0);
             if (FWD && own) {
                 s2 += q1.val * m1;
                 s3 += q2.val * m2;
                 s4 += q3.val * m2;
             }
-            d1[r] = q1.der * m1;
-            d2[r] = q2.der * m2;
-            d3[r] = q3.der * m2;
+            const f32x2 d1c = q1.der * m1, d2c = q2.der * m2, d3c = q3.der * m2;
+            if (BWD && own) {
+                const int j = r - 1;
+                // from the column to the left: lane - 1, or the edge row for lane 0
+                f32x2 in0 = {__shfl_up(d0c.x, 1, kWave), __shfl_up(d0c.y, 1, kWave)};
+                f32x2 in2 = {__shfl_up(d2p.x, 1, kWave), __shfl_up(d2p.y, 1, kWave)};
+                f32x2 in3 = {__shfl_up(d3c.x, 1, kWave), __shfl_up(d3c.y, 1, kWave)};
+                // (selects, not a branch: a divergent `if (lane == 0)` here cost 80 VGPRs)
+                const bool first = lane == 0;
+                in0.x = first ? edge_at(j) : in0.x;
+                in0.y = first ? edge_at(12 + j) : in0.y;
+                in2.x = first ? edge_at(4 + j) : in2.x;
+                in2.y = first ? edge_at(16 + j) : in2.y;
+                in3.x = first ? edge_at(8 + j) : in3.x;
+                in3.y = first ? edge_at(20 + j) : in3.y;
+                const f32x2 g = (in0 - d0c) * k0 + (d1p - d1c) * k1 + ((in2 - d2c) + (in3 - d3p)) * k2;
+                gu[j] += g.x;
+                gv[j] += g.y;
+            }
+            d1p = d1c;
+            d2p = d2c;
+            d3p = d3c;
+            p0 = n0;
+            p1 = n1;
         }
         if (FWD) {
             acc[1] = s1.x + s1.y;
             acc[2] = s2.x + s2.y;
             acc[3] = s3.x + s3.y;
             acc[4] = s4.x + s4.y;
-        }
-        if (BWD) {
-            const float k0 = S.k_smooth[0] * seed[0], k1 = S.k_smooth[1] * seed[0],
-                        k2 = S.k_smooth[2] * seed[0];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int r = j + 1;
-                // from the column to the left: lane - 1, or the edge row for lane 0
-                f32x2 in0 = {__shfl_up(d0[r].x, 1, kWave), __shfl_up(d0[r].y, 1, kWave)};
-                f32x2 in2 = {__shfl_up(d2[r - 1].x, 1, kWave), __shfl_up(d2[r - 1].y, 1, kWave)};
-                f32x2 in3 = {__shfl_up(d3[r].x, 1, kWave), __shfl_up(d3[r].y, 1, kWave)};
-                if (lane == 0) {
-                    in0 = f32x2{sE[wave][0][j], sE[wave][1][j]};
-                    in2 = f32x2{sE[wave][0][4 + j], sE[wave][1][4 + j]};
-                    in3 = f32x2{sE[wave][0][8 + j], sE[wave][1][8 + j]};
-                }
-                const f32x2 g = (in0 - d0[r]) * k0 + (d1[r - 1] - d1[r]) * k1 +
-                                ((in2 - d2[r]) + (in3 - d3[r - 1])) * k2;
-                gu[j] += g.x;
-                gv[j] += g.y;
-            }
         }
     }
     // ---- tail.  Waves 1..3 store their gradients and RETIRE; wave 0 alone
@@ -493,26 +466,22 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
         store_grads();
         return;
     }
+    // 7 integer atomics (no return) and the wave is done: the combination of
+    // the groups is loss_reduce_kernel's, ordered by the kernel boundary
     const int grp = k * P.N + n;
     if (lane < 7)
         accumulate(P.gacc + (size_t)grp * NGROUP + lane,
                    (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
-    if (!P.fold) {      // large grids: the wave does not wait for anything
-        store_grads();
-        return;
-    }
-    int old = 0;
-    if (lane == 0) old = arrive(P.counter, P.strict_fences);   // waits for the accumulator atomics only
     store_grads();
-    if (__shfl(old, 0, kWave) != (int)gridDim.x - 1) return;
-    final_terms<true>(P);
 }
 
-// The final combination as a launch of its own (one wave) for large grids:
-// there an arrival round trip per workgroup costs more than a launch (a CU
-// cannot start the next workgroup while its SIMD-0 slots are held by waves
-// waiting for their atomic's return).
-__global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P) { final_terms<false>(P); }
+// The final combination: one wave, a launch of its own.  (Folded into the
+// sweep -- last workgroup to arrive combines -- it saved ~1 us at batch 8 and
+// cost 30 us at batch 64: an arrival needs a store acknowledgement plus an
+// atomic round trip per workgroup, a CU cannot start the next workgroup while
+// its SIMD-0 slots are held by waves waiting for it, and the inlined
+// combination took the sweep from 96 to 160 VGPRs, 5 -> 3 waves per SIMD.)
+__global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P) { final_terms(P); }
 
 // Per-tile out-of-border pixel counts (utils/loss.py:101) ahead of the fused
 // forward+backward sweep: plain stores, one int per tile.  Workgroup 0 also
@@ -520,10 +489,8 @@ __global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P) { fi
 __device__ __forceinline__ void count_oob_block(const Params &P, int bid, int *red)
 {
     const int tid = threadIdx.x;
-    if (bid == 0 && P.counter) {     // accumulators and arrival counter of the sweep that follows
+    if (bid == 0 && P.gacc)      // group accumulators of the sweep that follows
         for (int i = tid; i < P.K * P.N * NGROUP; i += NT) P.gacc[i] = 0ull;
-        if (tid == 0) P.counter[0] = 0;
-    }
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -717,42 +684,28 @@ int build_params(const dvsof_loss_scale_t *sc, int K, int N, Params &P, int &tot
     return DVSOF_OK;
 }
 
-// workspace: [gacc K*N*NGROUP u64][oob_tile nb i32][counter i32]
-size_t ws_layout(int nb, int K, int N, size_t &tile_off, size_t &counter_off)
+// workspace: [gacc K*N*NGROUP u64][oob_tile nb i32]
+size_t ws_layout(int nb, int K, int N, size_t &tile_off)
 {
     size_t o = (size_t)K * N * NGROUP * sizeof(unsigned long long);
     tile_off = o;
     o += (size_t)nb * sizeof(int32_t);
-    o = (o + 15) & ~(size_t)15;
-    counter_off = o;
-    return o + 16;
+    return ((o + 15) & ~(size_t)15) + 16;
 }
 
 void bind_ws(Params &P, void *ws, int nb, float *terms, float *loss_out, const float *w,
              float loss_scale)
 {
-    size_t t, c;
-    ws_layout(nb, P.K, P.N, t, c);
+    size_t t;
+    ws_layout(nb, P.K, P.N, t);
     P.gacc = (unsigned long long *)ws;
     P.oob_tile = (int32_t *)((char *)ws + t);
-    P.counter = (int *)((char *)ws + c);
     P.terms = terms;
     P.loss_out = loss_out;
     for (int i = 0; i < 3; ++i) P.wts[i] = w ? w[i] : 0.f;
     P.loss_scale = loss_scale;
-    // DVSOF_LOSS_STRICT=1: additionally bracket the arrival counter with the
-    // memory model's agent-scope release / acquire fences (see arrive()).
-    // Measured on MI355X (round-2 stage a): the release fence in EVERY
-    // workgroup (buffer_wbl2 of an L2 full of freshly written gradients) took
-    // the fused loss from 126 to 291 us at batch 64.
-    static const bool strict = getenv("DVSOF_LOSS_STRICT") != nullptr;
-    P.strict_fences = strict ? 1 : 0;
     static const int dbg = getenv("DVSOF_LOSS_DBG") ? atoi(getenv("DVSOF_LOSS_DBG")) : 0;
     P.dbg = dbg;
-    // the last-arriving workgroup combines while one round of resident
-    // workgroups covers the grid (latency regime); a reduce launch above that
-    static const int fold_max = getenv("DVSOF_LOSS_FOLD_MAX") ? atoi(getenv("DVSOF_LOSS_FOLD_MAX")) : 1536;
-    P.fold = nb <= fold_max ? 1 : 0;
 }
 
 // Pyramid plan: fused single launch when the level sizes are non-decreasing
@@ -844,8 +797,8 @@ size_t dvsof_loss_workspace_bytes(const dvsof_loss_scale_t *sc, int K, int N)
     Params P = {};
     int nb = 0;
     if (build_params(sc, K, N, P, nb) != DVSOF_OK) return 0;
-    size_t g, c;
-    return ws_layout(nb, K, N, g, c);
+    size_t t;
+    return ws_layout(nb, K, N, t);
 }
 
 int dvsof_resize_bilinear_ac(const float *src, float *dst, int n, int hin, int win, int hout,
@@ -872,8 +825,8 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     const int rc = build_params(sc, K, N, P, nb);
     if (rc) return rc;
     if (!start || !stop || !terms || !oob || !ws) return DVSOF_EINVAL;
-    size_t g, c;
-    if (ws_bytes < ws_layout(nb, K, N, g, c)) return DVSOF_ENOSPACE;
+    size_t t;
+    if (ws_bytes < ws_layout(nb, K, N, t)) return DVSOF_ENOSPACE;
     P.start = start;
     P.stop = stop;
     bind_ws(P, ws, nb, terms, nullptr, nullptr, 1.f);
@@ -886,10 +839,8 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     DVSOF_LAUNCH_CHECK();
     hipLaunchKernelGGL((loss_main_kernel<true, false>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
     DVSOF_LAUNCH_CHECK();
-    if (!P.fold) {
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, as_stream(stream), P);
-        DVSOF_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, as_stream(stream), P);
+    DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
 
@@ -906,10 +857,8 @@ int dvsof_loss_bwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     P.start = start;
     P.stop = stop;
     P.gacc = nullptr;
-    P.counter = nullptr;
     P.oob_tile = nullptr;       // totals of the forward call
     P.terms = P.loss_out = nullptr;
-    P.strict_fences = 0;
     P.oob = const_cast<int32_t *>(oob);
     P.seeds_dev = seeds;
     hipLaunchKernelGGL((loss_main_kernel<false, true>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
@@ -932,8 +881,8 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
     if (!start || !stop || !w || !terms || !loss_out || !oob || !ws) return DVSOF_EINVAL;
     for (int k = 0; k < K; ++k)
         if (!sc[k].grad_flow) return DVSOF_EINVAL;
-    size_t g, c;
-    if (ws_bytes < ws_layout(nb, K, N, g, c)) return DVSOF_ENOSPACE;
+    size_t t;
+    if (ws_bytes < ws_layout(nb, K, N, t)) return DVSOF_ENOSPACE;
     P.start = start;
     P.stop = stop;
     bind_ws(P, ws, nb, terms, loss_out, w, loss_scale);
@@ -956,10 +905,8 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
     }
     hipLaunchKernelGGL((loss_main_kernel<true, true>), dim3(nb), dim3(NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
-    if (!P.fold) {
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, st, P);
-        DVSOF_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, st, P);
+    DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
 }  // namespace
