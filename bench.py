@@ -85,6 +85,9 @@ def parse():
     p.add_argument('--graph', action='store_true',
                    help='replay the step as ONE hipGraph launch (capture.CapturedTrainStep; '
                         'single GPU, bit-identical results)')
+    p.add_argument('--exec', dest='executor', action='store_true',
+                   help='replay the captured step through the step executor (csrc/exec.hip: plain '
+                        'launches from one C call on the eager schedule\'s two streams)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--cpu-samples', type=int, default=2)
@@ -117,31 +120,37 @@ class Harness:
         self.reducer = None
         self.i = 0
         self.captured = None
+        self.captured_all = {}
 
     def step(self):
-        if getattr(self.a, 'graph', False) and self.reducer is None:
+        if (getattr(self.a, 'graph', False) or getattr(self.a, 'executor', False)) \
+                and self.reducer is None:
             return self.graph_step()
         return self.eager_step()
 
     def graph_step(self):
-        batch = self.batches[self.i % len(self.batches)]
+        # one captured step per resident batch, bound to its buffers (no staging
+        # copy: the inputs are in HBM when the timed region starts, as for the
+        # eager step)
+        k = self.i % len(self.batches)
         self.i += 1
-        if self.captured is None:
+        if k not in self.captured_all:
             from dvs_of_training_framework_amd.capture import CapturedTrainStep
-            self.captured = CapturedTrainStep(self.model, self.losses, self.opt, [0.5, 1, 1],
-                                              self.device, batch)
+            self.captured = self.captured_all[k] = CapturedTrainStep(
+                self.model, self.losses, self.opt, [0.5, 1, 1], self.device, self.batches[k],
+                executor=bool(getattr(self.a, 'executor', False)), bind=True)
             loss = self.captured.first_loss
         else:
-            loss, _ = self.captured(batch)
+            loss, _ = self.captured_all[k]()
         self.sched.step()
         return loss
 
     def suspend_graph(self):
         """Per-launch instrumentation needs eager launches."""
-        if self.captured is not None:
-            self.captured.close()
-            self.captured = None
-        self.a.graph = False
+        for c in self.captured_all.values():
+            c.close()
+        self.captured, self.captured_all = None, {}
+        self.a.graph = self.a.executor = False
 
     def eager_step(self):
         from dvs_of_training_framework_amd.timer import FakeTimer
@@ -473,8 +482,11 @@ def main():
                     a.events or a.height * a.width,
                 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
         }
-    if rank == 0 and a.graph:
-        out['config']['launch'] = 'one hipGraph replay per step'
+    if rank == 0 and (a.graph or a.executor) and h.captured is not None:
+        ex = h.captured.executor
+        out['config']['launch'] = 'one hipGraph replay per step' if ex is None else (
+            f'step executor: {ex.kernels} kernels on {ex.lanes} streams {ex.lane_kernels}, '
+            f'{ex.events} events / {ex.waits} waits per step, one C call')
     if not a.no_roofline:
         h.suspend_graph()       # per-launch HIP events need eager launches
         roof = measure_roofline(h, dt / a.steps * 1e3)   # every rank runs the same steps

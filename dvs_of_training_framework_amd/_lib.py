@@ -35,6 +35,16 @@ _SIGNATURES = {
     'dvsof_comm_create': (_i, [ctypes.POINTER(_vp), _i, _i, _vp]),
     'dvsof_comm_destroy': (_i, [_vp]),
     'dvsof_allreduce_bucket': (_i, [_vp, _vp, _sz, _vp]),
+    'dvsof_exec_create': (_i, [_vp, ctypes.POINTER(_vp), _i,
+                               ctypes.POINTER(_vp)]),
+    'dvsof_exec_info': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i),
+                             ctypes.POINTER(_i), ctypes.POINTER(_i),
+                             ctypes.POINTER(_i), _i]),
+    'dvsof_exec_launch': (_i, [_vp, _vp]),
+    'dvsof_exec_calibrate': (_i, [_vp, _vp]),
+    'dvsof_exec_node': (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_f),
+                             ctypes.POINTER(_i), ctypes.c_char_p, _i]),
+    'dvsof_exec_destroy': (_i, [_vp]),
     'dvsof_count_image': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     'dvsof_voxelize_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                 _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

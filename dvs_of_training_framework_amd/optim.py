@@ -214,7 +214,7 @@ class FusedAdamW(_FusedBase):
             # stream gets there, so a row is rewritten only after its copy's
             # event has completed (the host runs several steps ahead)
             self._dyn_ring = [(torch.zeros(ng, 4, dtype=torch.float32).pin_memory(),
-                               torch.cuda.Event()) for _ in range(8)]
+                               torch.cuda.Event()) for _ in range(64)]
             self._dyn_next = 0
         self._use_dyn = True
 
@@ -223,7 +223,7 @@ class FusedAdamW(_FusedBase):
         sqrt(bc2)} of every group with one small asynchronous copy."""
         host, done = self._dyn_ring[self._dyn_next]
         self._dyn_next = (self._dyn_next + 1) % len(self._dyn_ring)
-        done.synchronize()      # the copy that last read this row (8 steps ago)
+        done.synchronize()      # the copy that last read this row (64 steps ago)
         buf = (ctypes.c_float * 3)()
         for gi, group in enumerate(self.param_groups):
             steps = set()

@@ -506,6 +506,41 @@ int dvsof_comm_create(void **comm, int world_size, int rank,
 int dvsof_comm_destroy(void *comm);
 int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
 
+/* ------------------------------------------------------------------ *
+ * Step executor (csrc/exec.hip): the loop body of the reference's train()
+ * (utils/training.py:138-167: model, loss, backward, optimizer.step) captured
+ * once per batch signature as a hipGraph and replayed as plain kernel
+ * launches from ONE C call, on the streams of the eager schedule.
+ *   graph         hipGraph_t of a stream capture; kernel (and empty) nodes
+ *                 only, else DVSOF_EINVAL; must outlive the executor
+ *   side_streams  hipStream_t of lanes 1..n_side (lane 0 = the stream given
+ *                 to dvsof_exec_launch); nodes are split into at most
+ *                 1 + n_side chains, one event per dependency across chains
+ *   dvsof_exec_calibrate  runs the step ONCE on `stream` alone with a timing
+ *                       event per kernel, waits for it (the only host
+ *                       synchronisation of the executor) and re-plans the
+ *                       lanes: lane 0 = longest path by measured time, so the
+ *                       chain that bounds the step never changes queues (a
+ *                       cross-queue dependency costs ~13 us); before it a
+ *                       greedy chain split is in effect.  It IS a step: same
+ *                       kernels, same results as dvsof_exec_launch
+ *   dvsof_exec_launch   side lanes start behind `stream`, `stream` continues
+ *                       behind every lane; nothing else synchronises
+ *   dvsof_exec_node     node i in launch order: lane, measured us, number of
+ *                       cross-lane waits, kernel name (diagnostics)
+ *   dvsof_exec_info     counts (any pointer may be NULL); lane_kernels[l] =
+ *                       kernels of lane l for l < max_lanes
+ * ------------------------------------------------------------------ */
+int dvsof_exec_create(void *graph, void *const *side_streams, int n_side,
+                      void **exec);
+int dvsof_exec_info(void *exec, int *n_kernels, int *n_lanes, int *n_events,
+                    int *n_waits, int *lane_kernels, int max_lanes);
+int dvsof_exec_calibrate(void *exec, void *stream);
+int dvsof_exec_launch(void *exec, void *stream);
+int dvsof_exec_node(void *exec, int i, int *lane, float *us, int *n_waits,
+                    char *name, int name_len);
+int dvsof_exec_destroy(void *exec);
+
 #ifdef __cplusplus
 }
 #endif

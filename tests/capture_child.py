@@ -1,8 +1,11 @@
 """Child process of tests/test_gpu_capture.py (a GPU fault must not take the
 test runner down): runs one scenario and prints one JSON line.
 
-  train   N training steps eagerly and N as hipGraph replays (no host sync
-          between steps), same seeds / batches / LR schedule: bitwise equality
+  train   N training steps eagerly and N as replays of the captured step by
+          the step executor (no host sync between steps), same seeds / batches
+          / LR schedule: bitwise equality
+  train_graph   the same through hipGraphLaunch (executor=False)
+  bind    two captured steps bound to resident batches, replayed alternately
   loop    training.train(capture=False) vs train(capture=True): logged scalars
   infer   OpticalFlow(graph=True): 30 replays back to back WITHOUT reading the
           result in between, then compared with the eager wrapper
@@ -46,7 +49,7 @@ def make(seed=5, C=5, dtype='f32'):
     return model, opt, sched, init_losses
 
 
-def scenario_train():
+def scenario_train(executor=True):
     from dvs_of_training_framework_amd.capture import CapturedTrainStep
     from dvs_of_training_framework_amd.loss import unit_backward
     from dvs_of_training_framework_amd.timer import FakeTimer
@@ -72,11 +75,16 @@ def scenario_train():
         torch.cuda.synchronize()
         return [float(v) for v in losses], [p.detach().clone() for p in model.parameters()]
 
+    info = {}
+
     def graphed():
         model, opt, sched, init_losses = make()
         ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
         step = CapturedTrainStep(model, ev, opt, [0.5, 1, 1], 'cuda', batches[0],
-                                 event_capacity=8192)
+                                 event_capacity=8192, executor=executor)
+        info.update(kernels=step.executor.kernels, lanes=step.executor.lanes,
+                    lane_kernels=step.executor.lane_kernels, events=step.executor.events,
+                    waits=step.executor.waits) if executor else None
         sched.step()
         losses = [step.first_loss]
         terms = None
@@ -97,7 +105,58 @@ def scenario_train():
             'eager_reproducible': l_e == l_e2 and all(torch.equal(a, b) for a, b in zip(w_e, w_e2)),
             'replays': replays, 'loss_first': l_e[0], 'loss_last': l_e[-1], 'graph_last': l_g[-1],
             'terms_finite': bool(np.isfinite(np.array(table)).all()),
-            'max_weight_diff': max(float((a - b).abs().max()) for a, b in zip(w_e, w_g))}
+            'max_weight_diff': max(float((a - b).abs().max()) for a, b in zip(w_e, w_g)),
+            'executor': info}
+
+
+def scenario_bind():
+    """Two captured steps BOUND to two resident batches (no staging copies),
+    sharing model and optimizer, replayed alternately by the step executor,
+    against the eager loop over the same batches."""
+    from dvs_of_training_framework_amd.capture import CapturedTrainStep
+    from dvs_of_training_framework_amd.loss import unit_backward
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch
+    B, H, W, steps = 2, 64, 64, 10
+    batches = [synthetic.to_torch(unique_pixel_batch(170 + i, B, H, W, 4096 - 500 * i), 'cuda')
+               for i in range(2)]
+
+    def eager():
+        model, opt, sched, init_losses = make()
+        ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+        losses = []
+        for i in range(steps):
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = process_minibatch(model, batches[i % 2], FakeTimer(), 'cuda', True, ev,
+                                           [0.5, 1, 1])
+            unit_backward(loss)
+            model.strict = False
+            opt.step()
+            sched.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return [float(v) for v in losses], [p.detach().clone() for p in model.parameters()]
+
+    def bound():
+        model, opt, sched, init_losses = make()
+        ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+        caps, losses = {}, []
+        for i in range(steps):
+            k = i % 2
+            if k not in caps:
+                caps[k] = CapturedTrainStep(model, ev, opt, [0.5, 1, 1], 'cuda', batches[k], bind=True)
+                losses.append(caps[k].first_loss.clone())
+            else:
+                losses.append(caps[k]()[0].clone())
+            sched.step()
+        torch.cuda.synchronize()
+        for c in caps.values():
+            c.close()
+        return [float(v) for v in losses], [p.detach().clone() for p in model.parameters()]
+    l_e, w_e = eager()
+    l_b, w_b = bound()
+    return {'losses_equal': l_e == l_b, 'weights_equal': all(torch.equal(a, b) for a, b in zip(w_e, w_b)),
+            'eager': l_e, 'bound': l_b}
 
 
 def scenario_loop():
@@ -151,5 +210,6 @@ def scenario_infer():
 
 
 if __name__ == '__main__':
-    out = {'train': scenario_train, 'loop': scenario_loop, 'infer': scenario_infer}[sys.argv[1]]()
+    out = {'train': scenario_train, 'train_graph': lambda: scenario_train(False),
+           'loop': scenario_loop, 'bind': scenario_bind, 'infer': scenario_infer}[sys.argv[1]]()
     print(json.dumps(out), flush=True)

@@ -25,9 +25,30 @@ def test_captured_training_step_is_bit_identical_to_the_eager_step():
     """12 steps over batches of varying event counts under an LR schedule
     (warm-up then decay): eager loop vs 1 eager + 11 replays.  Same losses,
     same weights, bit for bit; the eager loop itself is reproducible."""
+    r = run('train_graph')
+    assert r['eager_reproducible'], r
+    assert r['replays'] == 11 and r['terms_finite']
+    assert r['losses_equal'] and r['weights_equal'], r
+
+
+def test_step_executor_replays_the_capture_on_the_eager_streams():
+    """The same 12 steps with the captured graph replayed by the step executor
+    (csrc/exec.hip: plain launches from one C call, main stream + the weight-
+    gradient stream, an event per dependency across them): bit-identical to
+    the eager loop, and the two lanes of the eager schedule are recovered."""
     r = run('train')
     assert r['eager_reproducible'], r
     assert r['replays'] == 11 and r['terms_finite']
+    assert r['losses_equal'] and r['weights_equal'], r
+    x = r['executor']
+    assert x['lanes'] == 2 and min(x['lane_kernels']) >= 10, x
+    assert x['kernels'] == sum(x['lane_kernels']) and 0 < x['events'] <= x['waits'], x
+
+
+def test_bound_captured_steps_share_model_and_optimizer():
+    """bind=True: a resident batch's tensors are the step's input buffers (no
+    staging copies); two such steps replayed alternately == the eager loop."""
+    r = run('bind')
     assert r['losses_equal'] and r['weights_equal'], r
 
 

@@ -40,6 +40,27 @@ def main():
     t2 = time.perf_counter()
     print(f'graph: host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, with drain {1e3 * (t2 - t0) / n:.3f} ms/step')
     h.suspend_graph()
+    # the captured step through the step executor (csrc/exec.hip)
+    a.executor = True
+    for _ in range(3):
+        h.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        h.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    ex = h.captured.executor
+    print(f'exec:  host enqueue {1e3 * (t1 - t0) / n:.3f} ms/step, with drain {1e3 * (t2 - t0) / n:.3f} ms/step '
+          f'({ex.kernels} kernels, lanes {ex.lane_kernels}, {ex.events} events, {ex.waits} waits)')
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ex.replay()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f'exec:  dvsof_exec_launch alone {1e3 * (t1 - t0) / n:.3f} ms/call')
+    h.suspend_graph()
     import cProfile
     import pstats
     pr = cProfile.Profile()
