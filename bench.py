@@ -87,7 +87,13 @@ def parse():
                         'single GPU, bit-identical results)')
     p.add_argument('--exec', dest='executor', action='store_true',
                    help='replay the captured step through the step executor (csrc/exec.hip: plain '
-                        'launches from one C call on the eager schedule\'s two streams)')
+                        'launches from one C call on the eager schedule\'s two streams); the default '
+                        'on one GPU')
+    p.add_argument('--eager', action='store_true',
+                   help='enqueue every step from Python (the default under data parallelism, where '
+                        'the gradient exchange is not captured)')
+    p.add_argument('--no-other-modes', action='store_true',
+                   help='skip the short bf16x3 / bf16 runs reported beside the fp32 headline')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--cpu-samples', type=int, default=2)
@@ -422,6 +428,9 @@ def cpu_baseline(a):
 
 def main():
     a = parse()
+    if not (a.eager or a.graph):
+        a.executor = True       # (Harness.step falls back to eager launches under a reducer)
+    launch_mode = (a.graph, a.executor)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     from dvs_of_training_framework_amd import parallel
     rank, local, world = parallel.init_distributed('cuda')
@@ -482,6 +491,8 @@ def main():
                     a.events or a.height * a.width,
                 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
         }
+    if rank == 0:
+        out['config']['launch'] = 'eager: every kernel enqueued from Python'
     if rank == 0 and (a.graph or a.executor) and h.captured is not None:
         ex = h.captured.executor
         out['config']['launch'] = 'one hipGraph replay per step' if ex is None else (
@@ -492,6 +503,32 @@ def main():
         roof = measure_roofline(h, dt / a.steps * 1e3)   # every rank runs the same steps
         if rank == 0:
             out['roofline'] = roof
+    if rank == 0 and world == 1 and a.dtype == 'f32' and not a.no_other_modes:
+        # the same step in the reduced-precision matrix modes of configs[2] / [4]
+        # (short runs; the headline above is the exact-f32 path)
+        import copy
+        h.suspend_graph()
+        del h
+        others = {}
+        for dt in ('bf16x3', 'bf16'):
+            a2 = copy.copy(a)
+            a2.dtype, (a2.graph, a2.executor) = dt, launch_mode
+            h2 = Harness(a2, rank, device)
+            for _ in range(7):
+                h2.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                h2.step()
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t1) / 20
+            others[dt] = {'samples_per_s': round(a.batch / d2, 1), 'ms_per_step': round(d2 * 1e3, 3)}
+            h2.suspend_graph()
+            del h2
+        others['note'] = ('matrix-core operand modes, f32 storage and accumulation: bf16x3 = '
+                          'hi+lo split operands, three products (flows within 4e-6, gradients 9e-5 '
+                          'of the exact path); bf16 = operands rounded once')
+        out['other_modes'] = others
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a)

@@ -71,15 +71,21 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     long long *rowO = (long long *)(rowX + BM);   // [3][BM] output offsets (conv_epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63;
+    if (P.dbg & 512) return;      // probe: launch floor (dispatch + kernarg fetch)
     // wave-uniform values must live in SGPRs: otherwise hipcc wraps every
     // LDS-DMA in a waterfall loop over "possibly divergent" descriptors
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave8 & 3, wgrp = wave8 >> 2;   // wgrp = sub-slice owned (KSPLIT = 2)
     const int wr = wave / WCOLS, wc = wave % WCOLS;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // (An XCD-aware block -> tile map for the Winograd component GEMMs -- an XCD
+    // gets whole components, so weight and row tiles are fetched into one L2 --
+    // measured no change: 34.2 us either way; the probes below show the launch
+    // is bound by its fixed costs and by 2.25 workgroups per CU, not by memory.)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int m0 = bx * BM, n0 = by * BN;
     const int taps = P.ks * P.ks;
     // exact-tap phases differ 4x in work: the heavy ones are dispatched first
-    const int ph = P.ph_exact ? 3 - (int)blockIdx.z : (int)blockIdx.z, phy = ph >> 1, phx = ph & 1;
+    const int ph = P.ph_exact ? 3 - bz : bz, phy = ph >> 1, phx = ph & 1;
     const int kh = P.ph_exact ? 1 + phy : P.ks, kw = P.ph_exact ? 1 + phx : P.ks;
     const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
     const int nvec = P.ph_exact ? nvec_all / (P.ks * P.ks) * (kh * kw) : nvec_all;
@@ -112,6 +118,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         conv_row_offsets(P, rowO, BM, r, m < P.M, b, oy, ox, phy, phx);
     }
     __syncthreads();
+    if (P.dbg & 1024) return;     // probe: + row tables
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -436,6 +443,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+        if (P.dbg & 2048) return;     // probe: + ring prologue (first operands landed)
         load_frags(std::integral_constant<int, 0>{}, smem + wgrp * KPW * SUB);
 
         // The K loop in two parts: a steady part (every range test of a stage is

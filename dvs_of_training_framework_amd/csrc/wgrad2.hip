@@ -41,16 +41,17 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int taps = P.ks * P.ks;
 
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     int s = 0;
     for (int i = 1; i < P.nsrc; ++i)
-        if ((int)blockIdx.x >= P.tile_begin[i]) s = i;
+        if (bx >= P.tile_begin[i]) s = i;
     const GSrc &S = P.src[s];
     int coff = 0;
     for (int i = 0; i < s; ++i) coff += P.src[i].C;
-    const int f0 = ((int)blockIdx.x - P.tile_begin[s]) * BN;
+    const int f0 = (bx - P.tile_begin[s]) * BN;
     const int fmax = taps * S.C;
-    const int co0 = blockIdx.y * BMc;
-    const int ph = blockIdx.z / P.S, split = blockIdx.z - ph * P.S;
+    const int co0 = by * BMc;
+    const int ph = bz / P.S, split = bz - ph * P.S;
     const int phy = ph >> 1, phx = ph & 1;
     const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
     const int kbeg = split * P.klen;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
     // Bias gradient = column sums of gout: the first column tile's wc = 0 waves
     // add up the A fragments they read anyway (a few v_add per slice on 1/ntiles
     // of the workgroups; replaces a separate pass over gout).
-    const bool do_bias = P.dbias != nullptr && blockIdx.x == 0 && wc == 0;
+    const bool do_bias = P.dbias != nullptr && bx == 0 && wc == 0;
     float bsum[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) bsum[t] = 0.f;
@@ -278,11 +279,11 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
         for (int t = 0; t < TM; ++t) {
             const float v = bsum[t] + __shfl_xor(bsum[t], 32);
             const int co = co0 + (wr * TM + t) * 32 + lrow;
-            if (lh == 0 && co < P.Cout) P.dbias[(size_t)blockIdx.z * P.Cout + co] = v;
+            if (lh == 0 && co < P.Cout) P.dbias[(size_t)bz * P.Cout + co] = v;
         }
     }
     const size_t wsize = (size_t)P.Cout * taps * P.Cin_tot;
-    float *dW = P.dW + (size_t)blockIdx.z * wsize;
+    float *dW = P.dW + (size_t)bz * wsize;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int f = f0 + (wc * TN + tn) * 32 + lrow;

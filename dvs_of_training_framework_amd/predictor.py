@@ -25,6 +25,9 @@ from torch import nn
 
 from . import conv as C
 
+_SIDE_STREAMS = {}      # device index -> the second backward stream
+_EXTRA_STREAMS = {}     # device index -> further streams (DVSOF_WGRAD_STREAMS > 1)
+
 ENC_CH = (64, 128, 256, 512)
 DEC_CH = (256, 128, 64, 32)
 NUM_RES = 2
@@ -423,17 +426,24 @@ class Predictor(nn.Module):
         """Second stream of the backward (None: DVSOF_WGRAD_STREAM=0)."""
         if os.environ.get('DVSOF_WGRAD_STREAM', '1') == '0':
             return None
-        if getattr(self, '_wg_stream', None) is None or \
-                self._wg_stream.device != dev:
-            self._wg_stream = torch.cuda.Stream(device=dev)
-        return self._wg_stream
+        # ONE second stream per device, shared by every model of the process:
+        # ROCclr deals streams round-robin onto the hardware queues, and a third
+        # or fourth stream lands on the main stream's queue (the two backward
+        # chains then alternate instead of overlapping: 3.4 vs 2.4 ms per step
+        # measured on the third model built in one process)
+        key = torch.device(dev).index if torch.device(dev).index is not None \
+            else torch.cuda.current_device()
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        return _SIDE_STREAMS[key]
 
     def _extra_streams(self, dev):
         n = int(os.environ.get('DVSOF_WGRAD_STREAMS', '1')) - 1
-        have = getattr(self, '_wg_extra', [])
+        key = torch.device(dev).index if torch.device(dev).index is not None \
+            else torch.cuda.current_device()
+        have = _EXTRA_STREAMS.setdefault(key, [])
         while len(have) < n:
             have.append(torch.cuda.Stream(device=dev))
-        self._wg_extra = have
         return have[:max(n, 0)]
 
     def _buckets(self, params):
