@@ -57,6 +57,8 @@ _lib.register('dvsof_conv2d_kernel_generation', _i, [_P(ConvDesc), _i])
 _lib.register('dvsof_conv2d_fwd_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_dgrad_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])
+_lib.register('dvsof_conv2d_prepare16', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp])
+_lib.register('dvsof_to_bf16_many', _i, [_P(_vp), _P(_vp), _P(ctypes.c_size_t), _i, _vp])
 _lib.register('dvsof_conv2d_scratch_bytes', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_winograd_tile', _i, [_P(ConvDesc), _i])
 
@@ -77,6 +79,23 @@ def to_bf16(src):
                                          src.numel(), _lib.stream()),
                'dvsof_to_bf16')
     return dst
+
+
+def to_bf16_many(tensors):
+    """bf16 twins of up to 16 tensors in ONE launch (dvsof_to_bf16_many)."""
+    tensors = list(tensors)
+    out = [torch.empty(t.numel(), dtype=torch.bfloat16, device=t.device)
+           for t in tensors]
+    for i in range(0, len(tensors), 16):
+        chunk, dst = tensors[i:i + 16], out[i:i + 16]
+        n = len(chunk)
+        src_p = (_vp * n)(*[t.data_ptr() for t in chunk])
+        dst_p = (_vp * n)(*[t.data_ptr() for t in dst])
+        sizes = (ctypes.c_size_t * n)(*[t.numel() for t in chunk])
+        _lib.check(_lib.lib().dvsof_to_bf16_many(src_p, dst_p, sizes, n,
+                                                  _lib.stream()),
+                   'dvsof_to_bf16_many')
+    return out
 
 
 def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
@@ -162,11 +181,16 @@ def conv_fwd(desc, weight, bias, device, residual=None, want_z=False,
     return y, z
 
 
-def prepare(desc, weight, want_dgrad, phase_weights=None):
+def prepare(desc, weight, want_dgrad, phase_weights=None, want16=False):
     """-> (w_fwd, w_dgrad): prepared weights (dvsof_conv2d_prepare).  w_fwd is
     the raw weight itself unless the layer runs as sub-pixel phases.
     ``phase_weights``: the w_fwd of an earlier call -- only the data-gradient
-    form is made (from it, for a sub-pixel layer)."""
+    form is made (from it, for a sub-pixel layer).
+    ``want16``: -> (w_fwd, w_dgrad, w_fwd16, w_dgrad16), the bf16 twins written
+    by the kernels that make the forms (dvsof_conv2d_prepare16).  w_fwd16 is
+    None when nothing in this call touched the forward form (``phase_weights``
+    given, or a raw-weight layer without ``want_dgrad``: convert those with
+    ``to_bf16_many``)."""
     lib = _lib.lib()
     raw, nf, ndg, nscratch, _ = _plan(desc)
     dg_only = phase_weights is not None
@@ -178,6 +202,7 @@ def prepare(desc, weight, want_dgrad, phase_weights=None):
     w_dg = torch.empty(ndg, dtype=torch.float32, device=weight.device) \
         if want_dgrad else None
     make_fwd = not dg_only and nf != raw
+    w_fwd16 = w_dg16 = None
     if make_fwd or want_dgrad:
         # Winograd layer: both forms come from the raw weights
         wino = nscratch > 0
@@ -186,9 +211,24 @@ def prepare(desc, weight, want_dgrad, phase_weights=None):
         fp = w_fwd.data_ptr() if (nf != raw) else None
         if wino and dg_only:
             fp = None
-        _lib.check(lib.dvsof_conv2d_prepare(
-            ctypes.byref(desc), wp, fp, _lib.ptr(w_dg), _lib.stream()),
-            'dvsof_conv2d_prepare')
+        if want16 and not wino:
+            dev = weight.device
+            if make_fwd or (nf == raw and want_dgrad and not dg_only):
+                w_fwd16 = torch.empty(nf, dtype=torch.bfloat16, device=dev)
+            if want_dgrad:
+                w_dg16 = torch.empty(ndg, dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.dvsof_conv2d_prepare16(
+                ctypes.byref(desc), wp, fp, _lib.ptr(w_dg), _lib.ptr(w_fwd16),
+                _lib.ptr(w_dg16), _lib.stream()), 'dvsof_conv2d_prepare16')
+        else:
+            _lib.check(lib.dvsof_conv2d_prepare(
+                ctypes.byref(desc), wp, fp, _lib.ptr(w_dg), _lib.stream()),
+                'dvsof_conv2d_prepare')
+            if want16:      # Winograd forms (not used by the twins mode)
+                w_fwd16 = to_bf16(w_fwd) if make_fwd else None
+                w_dg16 = to_bf16(w_dg) if w_dg is not None else None
+    if want16:
+        return w_fwd, w_dg, w_fwd16, w_dg16
     return w_fwd, w_dg
 
 

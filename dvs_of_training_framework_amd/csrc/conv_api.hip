@@ -93,9 +93,13 @@ bool is_wino_wgrad(const dvsof_conv_desc_t *d)
 
 // Wf[ph][co][a][b][ci] = sum_{ky in S(py,a)} sum_{kx in S(px,b)} W[co][ky][kx][ci]
 // S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2}; ph = 2*py + px.
+// (every weight-form kernel below takes an optional bf16 destination: the twin
+// of the form it writes, for compute_dtype 'bf16s' -- a separate conversion
+// launch per form was 23 launches and 165 us of a 1.94 ms step at batch 8)
 __global__ __launch_bounds__(256) void subpixel_fwd_weights_kernel(const float *__restrict__ w,
                                                                    float *__restrict__ wf, int Cout,
-                                                                   int Ctot)
+                                                                   int Ctot,
+                                                                   unsigned short *__restrict__ wf16)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)Cout * Ctot) return;
@@ -123,14 +127,17 @@ __global__ __launch_bounds__(256) void subpixel_fwd_weights_kernel(const float *
                     const float *rr = r[2 * py + a];
                     const int q = 2 * px + b;
                     const float v = q == 0 ? rr[0] : q == 1 ? rr[1] + rr[2] : q == 2 ? rr[0] + rr[1] : rr[2];
-                    wf[((((size_t)(2 * py + px) * Cout + co) * 2 + a) * 2 + b) * Ctot + ci] = v;
+                    const size_t o = ((((size_t)(2 * py + px) * Cout + co) * 2 + a) * 2 + b) * Ctot + ci;
+                    wf[o] = v;
+                    if (wf16) wf16[o] = bf16_bits(v);
                 }
 }
 
 // Wd[ci][ty][tx][co] = Wf[ph][co][a][b][ci], ty -> (py,a): 0->(1,1) 1->(0,1) 2->(1,0) 3->(0,0)
 __global__ __launch_bounds__(256) void subpixel_dgrad_weights_kernel(const float *__restrict__ wf,
                                                                      float *__restrict__ wd,
-                                                                     int Cout, int Ctot)
+                                                                     int Cout, int Ctot,
+                                                                     unsigned short *__restrict__ wd16)
 {
     __shared__ float tile[32][33];
     const int z = blockIdx.z, ty = z >> 2, tx = z & 3;
@@ -146,16 +153,23 @@ __global__ __launch_bounds__(256) void subpixel_dgrad_weights_kernel(const float
     __syncthreads();
     for (int r = ly; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + lx;
-        if (ci < Ctot && co < Cout) wd[((size_t)ci * 16 + z) * Cout + co] = tile[lx][r];
+        if (ci < Ctot && co < Cout) {
+            const size_t o = ((size_t)ci * 16 + z) * Cout + co;
+            wd[o] = tile[lx][r];
+            if (wd16) wd16[o] = bf16_bits(tile[lx][r]);
+        }
     }
 }
 
 // Stride-2 3x3/pad-1 data gradient as four input-parity phases of 2x2 taps:
 // Wp[ph][ci][a][b][co] = W[co][ky(py,a)][kx(px,b)][ci], ky(0,0)=1, ky(0,1)=none,
 // ky(1,0)=2, ky(1,1)=0 (unused taps are zero).  ph = 2*py + px.
+// w16: bf16 twin of the RAW weights (each raw tap is read by exactly one z)
 __global__ __launch_bounds__(256) void stride2_dgrad_weights_kernel(const float *__restrict__ w,
                                                                     float *__restrict__ wp,
-                                                                    int Cout, int Ctot)
+                                                                    int Cout, int Ctot,
+                                                                    unsigned short *__restrict__ wp16,
+                                                                    unsigned short *__restrict__ w16)
 {
     __shared__ float tile[32][33];
     const int z = blockIdx.z;            // ph*4 + a*2 + b
@@ -166,14 +180,22 @@ __global__ __launch_bounds__(256) void stride2_dgrad_weights_kernel(const float 
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     for (int r = ly; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + lx;
-        tile[r][lx] = (used && co < Cout && ci < Ctot)
-                          ? w[((size_t)co * 9 + ky * 3 + kx) * Ctot + ci] : 0.f;
+        float v = 0.f;
+        if (used && co < Cout && ci < Ctot) {
+            const size_t o = ((size_t)co * 9 + ky * 3 + kx) * Ctot + ci;
+            v = w[o];
+            if (w16) w16[o] = bf16_bits(v);
+        }
+        tile[r][lx] = v;
     }
     __syncthreads();
     for (int r = ly; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + lx;
-        if (ci < Ctot && co < Cout)
-            wp[(((size_t)ph * Ctot + ci) * 4 + a * 2 + b) * Cout + co] = tile[lx][r];
+        if (ci < Ctot && co < Cout) {
+            const size_t o = (((size_t)ph * Ctot + ci) * 4 + a * 2 + b) * Cout + co;
+            wp[o] = tile[lx][r];
+            if (wp16) wp16[o] = bf16_bits(tile[lx][r]);
+        }
     }
 }
 
@@ -185,7 +207,9 @@ bool is_stride2_phased(const dvsof_conv_desc_t *d)
 
 __global__ __launch_bounds__(256) void flip_transpose_kernel(const float *__restrict__ w,
                                                              float *__restrict__ wt, int Cout,
-                                                             int taps, int Ctot)
+                                                             int taps, int Ctot,
+                                                             unsigned short *__restrict__ wt16,
+                                                             unsigned short *__restrict__ w16)
 {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z;
@@ -193,13 +217,22 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float *__rest
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
-        tile[r][tx] = (co < Cout && ci < Ctot) ? w[((size_t)co * taps + tap) * Ctot + ci] : 0.f;
+        float v = 0.f;
+        if (co < Cout && ci < Ctot) {
+            const size_t o = ((size_t)co * taps + tap) * Ctot + ci;
+            v = w[o];
+            if (w16) w16[o] = bf16_bits(v);
+        }
+        tile[r][tx] = v;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + tx;
-        if (ci < Ctot && co < Cout)
-            wt[((size_t)ci * taps + (taps - 1 - tap)) * Cout + co] = tile[tx][r];
+        if (ci < Ctot && co < Cout) {
+            const size_t o = ((size_t)ci * taps + (taps - 1 - tap)) * Cout + co;
+            wt[o] = tile[tx][r];
+            if (wt16) wt16[o] = bf16_bits(tile[tx][r]);
+        }
     }
 }
 
@@ -359,6 +392,37 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ 
         } else {
             for (size_t j = i; j < n; ++j) dst[j] = bf16_bits(src[j]);
         }
+    }
+}
+
+// several tensors in one launch (the raw-weight twins of a step): a workgroup
+// converts 2048 elements of the tensor its index falls into
+constexpr int BF16_MANY_MAX = 16;
+struct Bf16Many {
+    const float *src[BF16_MANY_MAX];
+    unsigned short *dst[BF16_MANY_MAX];
+    size_t n[BF16_MANY_MAX];
+    unsigned block_begin[BF16_MANY_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void to_bf16_many_kernel(const Bf16Many J)
+{
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8), aligned(4)));
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < BF16_MANY_MAX; ++i)
+        if (i < J.count && blockIdx.x >= J.block_begin[i]) t = i;
+    const float *src = J.src[t];
+    unsigned short *dst = J.dst[t];
+    const size_t n = J.n[t];
+    const size_t i = ((size_t)(blockIdx.x - J.block_begin[t]) * 256 + threadIdx.x) * 8;
+    if (i + 7 < n) {
+        const f32x4 a = *(const f32x4u *)(src + i), b = *(const f32x4u *)(src + i + 4);
+        const u16x8 h = {bf16_bits(a[0]), bf16_bits(a[1]), bf16_bits(a[2]), bf16_bits(a[3]),
+                         bf16_bits(b[0]), bf16_bits(b[1]), bf16_bits(b[2]), bf16_bits(b[3])};
+        *(u16x8 *)(dst + i) = h;
+    } else {
+        for (size_t j = i; j < n; ++j) dst[j] = bf16_bits(src[j]);
     }
 }
 
@@ -667,12 +731,23 @@ size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *d)
     return (size_t)d->Cout * Ctot * d->ksize * d->ksize;
 }
 
-int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float *w_fwd,
-                         float *w_dgrad, void *stream)
+static int flip_transpose16(const float *w, float *wt, int Cout, int ksize, int Ctot,
+                            unsigned short *wt16, unsigned short *w16, void *stream);
+int dvsof_to_bf16(const float *src, void *dst, size_t n, void *stream);
+
+// w_fwd16 / w_dgrad16 (optional): bf16 twins of the two forms, written by the
+// kernels that make the forms.  For a layer whose forward form is the raw
+// weight, w_fwd16 is the raw weight's twin (emitted by the data-gradient form
+// kernel, which reads every raw element once; a conversion launch if no
+// data-gradient form is asked for).
+int dvsof_conv2d_prepare16(const dvsof_conv_desc_t *d, const float *weight, float *w_fwd,
+                           float *w_dgrad, void *w_fwd16_, void *w_dgrad16_, void *stream)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return DVSOF_EINVAL;
     hipStream_t st = as_stream(stream);
+    unsigned short *w_fwd16 = (unsigned short *)w_fwd16_, *w_dgrad16 = (unsigned short *)w_dgrad16_;
+    if (w_dgrad16 && !w_dgrad) return DVSOF_EINVAL;
     if (is_subpixel(d)) {
         if (!w_fwd) return DVSOF_EINVAL;
         // weight == NULL: w_fwd already holds the phase kernels (made by an
@@ -681,37 +756,46 @@ int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float 
         if (weight) {
             const size_t n = (size_t)d->Cout * Ctot;
             hipLaunchKernelGGL(subpixel_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)),
-                               dim3(256), 0, st, weight, w_fwd, d->Cout, Ctot);
+                               dim3(256), 0, st, weight, w_fwd, d->Cout, Ctot, w_fwd16);
             DVSOF_LAUNCH_CHECK();
+        } else if (w_fwd16) {
+            const int rc = dvsof_to_bf16(w_fwd, w_fwd16, dvsof_conv2d_fwd_weight_elems(d), stream);
+            if (rc) return rc;
         }
         if (w_dgrad) {
             dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);
             hipLaunchKernelGGL(subpixel_dgrad_weights_kernel, grid, dim3(256), 0, st,
-                               (const float *)w_fwd, w_dgrad, d->Cout, Ctot);
+                               (const float *)w_fwd, w_dgrad, d->Cout, Ctot, w_dgrad16);
             DVSOF_LAUNCH_CHECK();
         }
         return DVSOF_OK;
     }
     if (is_wino(d)) {   // either form (or both) from the raw weights
         if (!weight || (!w_fwd && !w_dgrad)) return DVSOF_EINVAL;
+        if (w_fwd16 || w_dgrad16) return DVSOF_EINVAL;   // the bf16-twin mode runs these layers direct
         return wino_prepare(weight, w_fwd, w_dgrad, d->Cout, Ctot, d->B, d->H, d->W, d->mfma == 2 ? 2 : 0, st);
     }
     if (!weight) return DVSOF_EINVAL;
-    if (is_stride2_phased(d) && w_dgrad) {
-        if (w_fwd && w_fwd != weight)
-            DVSOF_HIP_TRY(hipMemcpyAsync(w_fwd, weight, (size_t)d->Cout * 9 * Ctot * sizeof(float),
-                                         hipMemcpyDeviceToDevice, st));
-        dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);
-        hipLaunchKernelGGL(stride2_dgrad_weights_kernel, grid, dim3(256), 0, st, weight, w_dgrad,
-                           d->Cout, Ctot);
-        DVSOF_LAUNCH_CHECK();
-        return DVSOF_OK;
-    }
+    // the forward form is the raw weight (or a copy of it)
     if (w_fwd && w_fwd != weight)
         DVSOF_HIP_TRY(hipMemcpyAsync(w_fwd, weight, dvsof_conv2d_fwd_weight_elems(d) * sizeof(float),
                                      hipMemcpyDeviceToDevice, st));
-    if (w_dgrad) return dvsof_weight_flip_transpose(weight, w_dgrad, d->Cout, d->ksize, Ctot, stream);
+    if (is_stride2_phased(d) && w_dgrad) {
+        dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);
+        hipLaunchKernelGGL(stride2_dgrad_weights_kernel, grid, dim3(256), 0, st, weight, w_dgrad,
+                           d->Cout, Ctot, w_dgrad16, w_fwd16);
+        DVSOF_LAUNCH_CHECK();
+        return DVSOF_OK;
+    }
+    if (w_dgrad) return flip_transpose16(weight, w_dgrad, d->Cout, d->ksize, Ctot, w_dgrad16, w_fwd16, stream);
+    if (w_fwd16) return dvsof_to_bf16(weight, w_fwd16, dvsof_conv2d_fwd_weight_elems(d), stream);
     return DVSOF_OK;
+}
+
+int dvsof_conv2d_prepare(const dvsof_conv_desc_t *d, const float *weight, float *w_fwd,
+                         float *w_dgrad, void *stream)
+{
+    return dvsof_conv2d_prepare16(d, weight, w_fwd, w_dgrad, nullptr, nullptr, stream);
 }
 
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind);
@@ -772,16 +856,22 @@ int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)
     return DVSOF_EINVAL;
 }
 
-int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize, int Ctot,
-                                void *stream)
+static int flip_transpose16(const float *w, float *wt, int Cout, int ksize, int Ctot,
+                            unsigned short *wt16, unsigned short *w16, void *stream)
 {
     if (!w || !wt || Cout < 1 || ksize < 1 || Ctot < 1) return DVSOF_EINVAL;
     const int taps = ksize * ksize;
     dim3 grid((Ctot + 31) / 32, (Cout + 31) / 32, taps);
     hipLaunchKernelGGL(flip_transpose_kernel, grid, dim3(256), 0, as_stream(stream), w, wt, Cout,
-                       taps, Ctot);
+                       taps, Ctot, wt16, w16);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
+}
+
+int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize, int Ctot,
+                                void *stream)
+{
+    return flip_transpose16(w, wt, Cout, ksize, Ctot, nullptr, nullptr, stream);
 }
 
 #define HEAD_DISPATCH(KERNEL, nb, ...)                                                         \
@@ -845,6 +935,30 @@ int dvsof_to_bf16(const float *src, void *dst, size_t n, void *stream)
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), src,
                        (unsigned short *)dst, n);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_to_bf16_many(const float *const *src, void *const *dst, const size_t *n, int count,
+                       void *stream)
+{
+    if (count < 0 || count > BF16_MANY_MAX || (count && (!src || !dst || !n))) return DVSOF_EINVAL;
+    if (count == 0) return DVSOF_OK;
+    Bf16Many J = {};
+    size_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!src[i] || !dst[i]) return DVSOF_EINVAL;
+        J.src[i] = src[i];
+        J.dst[i] = (unsigned short *)dst[i];
+        J.n[i] = n[i];
+        J.block_begin[i] = (unsigned)blocks;
+        blocks += (n[i] + 2047) / 2048;
+    }
+    J.count = count;
+    J.block_begin[count] = (unsigned)blocks;
+    if (blocks == 0) return DVSOF_OK;
+    if (blocks > 0x7fffffffu) return DVSOF_EINVAL;
+    hipLaunchKernelGGL(to_bf16_many_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), J);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

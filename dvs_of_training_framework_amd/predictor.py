@@ -73,6 +73,12 @@ class _Named(nn.Module):
             self.add_module(k, v)
 
 
+def _prep(desc, weight, want_dgrad, phase_weights=None, want16=False):
+    """conv.prepare -> always (w_fwd, w_dgrad, w_fwd16, w_dgrad16)."""
+    out = C.prepare(desc, weight, want_dgrad, phase_weights, want16)
+    return out if want16 else (out[0], out[1], None, None)
+
+
 def _phys(w):
     """Physical [Cout][k][k][Cin] buffer of a channels_last OIHW weight."""
     assert w.permute(0, 2, 3, 1).is_contiguous(), \
@@ -131,12 +137,21 @@ class _PredictorFn(torch.autograd.Function):
                 for li, srcs_, hh, ww, cout_, wgt_, up_ in specs:
                     d_ = C.make_desc(srcs_, B, hh, ww, cout_, 3, 1, 1, up_, act,
                                      module.mfma)
-                    w_f, _ = C.prepare(d_, _phys(wgt_), False)
+                    w_f, _, w_f16, _ = _prep(d_, _phys(wgt_), False,
+                                                 want16=twins)
                     if w_f is not wgt_:
-                        pre[li] = (w_f, C.to_bf16(w_f) if twins else None)
+                        pre[li] = (w_f, w_f16)
             pre_ready = torch.cuda.Event()
             pre_ready.record(side)
         waited = [False]
+        # bf16-twins mode: the twins of the weights that are used as they are
+        # (stride-2 encoder layers, direct residual layers) in ONE launch; the
+        # twins of prepared forms come from the kernels that make the forms
+        raw16 = {}
+        if twins:
+            raws = [e_[0] for e_ in enc] + [r_[j] for r_ in res for j in (0, 2)]
+            raw16 = {id(w_): t_ for w_, t_ in
+                     zip(raws, C.to_bf16_many([_phys(w_) for w_ in raws]))}
 
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
@@ -163,16 +178,16 @@ class _PredictorFn(torch.autograd.Function):
                         ev.record(main)
                         side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    _, w_dg = C.prepare(d, _phys(wgt), True,
-                                        phase_weights=w_fwd)
-                    if twins:
-                        w_dg16 = C.to_bf16(w_dg)
+                    _, w_dg, _, w_dg16 = _prep(d, _phys(wgt), True,
+                                                   phase_weights=w_fwd,
+                                                   want16=twins)
             else:
-                w_fwd, w_dg = C.prepare(d, _phys(wgt), need_dg)
-                if twins and w_dg is not None:
-                    w_dg16 = C.to_bf16(w_dg)
+                w_fwd, w_dg, w_fwd16, w_dg16 = _prep(
+                    d, _phys(wgt), need_dg, want16=twins)
             if twins and w_fwd16 is None:
-                w_fwd16 = C.to_bf16(w_fwd)
+                w_fwd16 = raw16.get(id(wgt))
+                if w_fwd16 is None or w_fwd is not wgt:
+                    w_fwd16 = C.to_bf16(w_fwd)
             y, z = C.conv_fwd(d, w_fwd, bias, dev, residual, mish,
                               keep_input_transform=want_grad,
                               weight16=w_fwd16)

@@ -419,6 +419,16 @@ int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow,
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements: the bf16 twins of
  * the prepared weights for mfma mode 3 */
 int dvsof_to_bf16(const float *src, void *dst, size_t n, void *stream);
+/* up to 16 tensors in ONE launch (host arrays of device pointers / sizes) */
+int dvsof_to_bf16_many(const float *const *host_src, void *const *host_dst,
+                       const size_t *host_n, int count, void *stream);
+/* dvsof_conv2d_prepare that also writes the bf16 twins of the forms it makes
+ * (compute mode 3, "bf16 twins"), from the same kernels: w_fwd16 = twin of the
+ * forward form -- of the RAW weight where that is the forward form --,
+ * w_dgrad16 = twin of the data-gradient form; either may be NULL. */
+int dvsof_conv2d_prepare16(const dvsof_conv_desc_t *desc, const float *weight,
+                           float *w_fwd, float *w_dgrad, void *w_fwd16,
+                           void *w_dgrad16, void *stream);
 
 /* dz = dy * act'(actsrc), n elements (dz may alias dy) */
 int dvsof_act_bwd(const float *dy, const float *actsrc, int act, float *dz,

@@ -9,7 +9,7 @@ O=$R/gpurun_out
 python3 $R/bench.py > $O/${S}_bench.json 2> $O/${S}_bench.err
 DVSOF_WGRAD_STREAM=0 python3 $R/tools/conv_bench.py > $O/${S}_conv_per_launch_serial.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${S}_stats -o s -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${S}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${S}_stats -o s -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes > $O/${S}_stats.log 2>&1
 cd $R
 tools/pmc.sh ${S}_pmc_fetch FETCH_SIZE
 tools/pmc.sh ${S}_pmc_write WRITE_SIZE
