@@ -510,7 +510,7 @@ def main():
         h.suspend_graph()
         del h
         others = {}
-        for dt in ('bf16x3', 'bf16'):
+        for dt in ('bf16x3', 'bf16', 'bf16s'):
             a2 = copy.copy(a)
             a2.dtype, (a2.graph, a2.executor) = dt, launch_mode
             h2 = Harness(a2, rank, device)
@@ -525,9 +525,10 @@ def main():
             others[dt] = {'samples_per_s': round(a.batch / d2, 1), 'ms_per_step': round(d2 * 1e3, 3)}
             h2.suspend_graph()
             del h2
-        others['note'] = ('matrix-core operand modes, f32 storage and accumulation: bf16x3 = '
-                          'hi+lo split operands, three products (flows within 4e-6, gradients 9e-5 '
-                          'of the exact path); bf16 = operands rounded once')
+        others['note'] = ('matrix-core operand modes with f32 accumulation: bf16x3 = hi+lo split '
+                          'operands, three products (flows within 4e-6, gradients 9e-5 of the exact '
+                          'path); bf16 = f32 storage, operands rounded once; bf16s = bf16 twins of '
+                          'activations / gradients / weight forms streamed through LDS')
         out['other_modes'] = others
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
