@@ -98,9 +98,14 @@ def to_bf16_many(tensors):
     return out
 
 
+UP_NONE, UP_NEAREST, UP_ZERO = 0, 1, 2     # dvsof_conv_desc_t.upsample
+
+
 def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
               act=ACT_NONE, mfma=MFMA_F32):
-    """srcs: list of (tensor, C, layout[, bf16 twin])."""
+    """srcs: list of (tensor, C, layout[, bf16 twin]).  upsample: False / True
+    (2x nearest) or UP_ZERO (2x zero insertion: the layer is a transposed
+    convolution with stride 2 -- one NHWC source, 3x3, pad 1)."""
     d = ConvDesc()
     d.nsrc = len(srcs)
     for i, src in enumerate(srcs):
@@ -110,7 +115,8 @@ def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
         d.src[i].layout = layout
         d.src[i].p16 = _lib.ptr(src[3]) if len(src) > 3 else None
     d.B, d.H, d.W = B, H, W
-    d.upsample = 1 if upsample else 0
+    d.upsample = UP_ZERO if upsample == UP_ZERO and upsample is not True \
+        else (1 if upsample else 0)
     d.ksize, d.stride, d.pad = ksize, stride, pad
     d.Cout, d.act, d.mfma = Cout, act, mfma
     return d

@@ -54,7 +54,14 @@ bool desc_ok(const dvsof_conv_desc_t *d, int &Ctot, int &Ho, int &Wo)
     if (!d || d->nsrc < 1 || d->nsrc > 3 || d->B < 1 || d->H < 1 || d->W < 1) return false;
     if (d->ksize != 1 && d->ksize != 3 && d->ksize != 5) return false;
     if (d->stride != 1 && d->stride != 2) return false;
+    if (d->upsample < 0 || d->upsample > 2) return false;
     if (d->upsample && d->stride != 1) return false;
+    // upsample = 2: zero insertion (transposed convolution).  One NHWC source of
+    // whole 16-channel K slices, 3x3 taps, pad 1: the phased MFMA form below
+    if (d->upsample == 2 &&
+        !(d->ksize == 3 && d->pad == 1 && d->nsrc == 1 && d->src[0].layout == DVSOF_NHWC &&
+          d->src[0].C % BK == 0 && d->mfma != 3))
+        return false;
     if (d->Cout < 1 || d->pad < 0 || d->pad >= d->ksize) return false;
     Ctot = 0;
     for (int i = 0; i < d->nsrc; ++i) {
@@ -72,8 +79,15 @@ bool desc_ok(const dvsof_conv_desc_t *d, int &Ctot, int &Ho, int &Wo)
 
 bool is_subpixel(const dvsof_conv_desc_t *d)
 {   // up2 + 3x3/pad1/stride1 == four 2x2 phase convolutions on the low-res input
-    return d->upsample && d->ksize == 3 && d->pad == 1 && d->stride == 1;
+    return d->upsample == 1 && d->ksize == 3 && d->pad == 1 && d->stride == 1;
 }
+
+// zero-insertion 2x + 3x3/pad 1 = transposed convolution with stride 2:
+// y[Y][X] = sum_k W[ky][kx] xz[Y+ky-1][X+kx-1], xz[2i][2j] = x[i][j], else 0
+// (torch: conv_transpose2d(x, W.flip(2,3).transpose(0,1), stride 2, padding 1,
+// output_padding 1)).  Evaluated as four output-parity phases of (1+py)(1+px)
+// taps on the low-resolution input -- the adjoint of the phased stride-2 layer.
+bool is_transposed(const dvsof_conv_desc_t *d) { return d->upsample == 2; }
 
 // wide 3x3 stride-1 layer evaluated as Winograd F(2x2,3x3) (winograd.hip)
 bool is_wino(const dvsof_conv_desc_t *d)
@@ -197,6 +211,61 @@ __global__ __launch_bounds__(256) void stride2_dgrad_weights_kernel(const float 
             if (wp16) wp16[o] = bf16_bits(tile[lx][r]);
         }
     }
+}
+
+// Transposed-convolution forward as four output-parity phases of 2x2 taps:
+// Wt[ph][co][a][b][ci] = W[co][ky(py,a)][kx(px,b)][ci], ky(0,0)=1, ky(0,1)=none,
+// ky(1,0)=0, ky(1,1)=2 (unused taps are zero).  ph = 2*py + px.
+__global__ __launch_bounds__(256) void transposed_fwd_weights_kernel(const float *__restrict__ w,
+                                                                     float *__restrict__ wt,
+                                                                     int Cout, int Ctot,
+                                                                     unsigned short *__restrict__ wt16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Cout * Ctot) return;
+    const int ci = (int)(i % Ctot), co = (int)(i / Ctot);
+#pragma unroll
+    for (int z = 0; z < 16; ++z) {
+        const int ph = z >> 2, a = (z >> 1) & 1, b = z & 1, py = ph >> 1, px = ph & 1;
+        const int ky = py ? (a ? 2 : 0) : (a ? -1 : 1), kx = px ? (b ? 2 : 0) : (b ? -1 : 1);
+        const float v = (ky >= 0 && kx >= 0) ? w[((size_t)co * 9 + ky * 3 + kx) * Ctot + ci] : 0.f;
+        const size_t o = ((((size_t)ph * Cout + co) * 2 + a) * 2 + b) * Ctot + ci;
+        wt[o] = v;
+        if (wt16) wt16[o] = bf16_bits(v);
+    }
+}
+
+// per-channel sum of an NHWC tensor, fixed order: partial sums per workgroup
+// (64 pixels per pass and lane group), then one wave per channel
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float *__restrict__ g,
+                                                                  long long npix, int C,
+                                                                  float *__restrict__ part)
+{
+    // thread t owns channel c = t % C of pixel rows t / C, t / C + 256 / C, ... (C <= 256)
+    const int per = 256 / C, c = threadIdx.x % C, r = threadIdx.x / C;
+    float a = 0.f;
+    if (r < per)
+        for (long long p = (long long)blockIdx.x * per + r; p < npix; p += (long long)gridDim.x * per)
+            a += g[p * C + c];
+    __shared__ float sm[256];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int j = 0; j < per; ++j) t += sm[j * C + threadIdx.x];
+        part[(size_t)blockIdx.x * C + threadIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float *__restrict__ part,
+                                                                int nblocks, int C,
+                                                                float *__restrict__ out)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double a = 0;
+    for (int b = lane; b < nblocks; b += 64) a += (double)part[(size_t)b * C + c];
+    a = wave_sum(a);
+    if (lane == 0) out[c] = (float)a;
 }
 
 bool is_stride2_phased(const dvsof_conv_desc_t *d)
@@ -519,6 +588,11 @@ extern "C" {
 
 int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize, int Ctot,
                                 void *stream);
+static int flip_transpose16(const float *w, float *wt, int Cout, int ksize, int Ctot,
+                            unsigned short *wt16, unsigned short *w16, void *stream);
+size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d);
+int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dweight, float *dbias,
+                       void *ws, size_t ws_bytes, void *stream);
 
 int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const float *bias,
                      const float *residual, float *y, float *z, void *stream)
@@ -566,6 +640,23 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
         P.M = d->B * d->H * d->W;
         P.nph = 4;
         P.ph_pad = 1;
+        P.w_phase_stride = (long long)d->Cout * 4 * Ctot;
+        P.dst[0].sy = 2 * Wo * d->Cout;
+        P.dst[0].sx = 2 * d->Cout;
+        P.dst[0].ph_y = Wo * d->Cout;
+        P.dst[0].ph_x = d->Cout;
+    }
+    if (is_transposed(d)) {   // `weight` is the prepared Wt[4][Cout][2][2][Ctot]
+        P.up = UP_NONE;
+        P.Hv = d->H;
+        P.Wv = d->W;
+        P.Ho = d->H;          // rows = low-resolution positions, four output phases
+        P.Wo = d->W;
+        P.ks = 2;
+        P.pad = 0;
+        P.M = d->B * d->H * d->W;
+        P.nph = 4;
+        P.ph_exact = 1;
         P.w_phase_stride = (long long)d->Cout * 4 * Ctot;
         P.dst[0].sy = 2 * Wo * d->Cout;
         P.dst[0].sx = 2 * d->Cout;
@@ -641,6 +732,17 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
             P.dst[i].sy *= 2;
             P.dst[i].sx *= 2;
         }
+    } else if (is_transposed(d)) {
+        // adjoint of the zero insertion: a plain stride-2 3x3/pad-1 convolution
+        // of gout (2H x 2W) with the flip-transposed weights
+        P.up = UP_NONE;
+        P.Hv = Ho;
+        P.Wv = Wo;
+        P.Ho = d->H;
+        P.Wo = d->W;
+        P.quad = 0;
+        P.stride = 2;
+        P.pad = 1;
     } else if (d->upsample) {  // rows = upsampled pixels, quad-summed to H x W
         P.up = UP_NONE;
         P.Hv = Ho;
@@ -676,10 +778,49 @@ size_t dvsof_conv2d_scratch_bytes(const dvsof_conv_desc_t *d)
     return wino_scratch_floats(d->B, d->H, d->W, Ctot, d->Cout, d->mfma == 2 ? 2 : 0) * sizeof(float);
 }
 
+// Transposed layer T: [B,H,W,Ctot] -> [B,2H,2W,Cout].  Its weight gradient is
+// the weight gradient of the adjoint stride-2 layer S: [B,2H,2W,Cout] ->
+// [B,H,W,Ctot] with the roles swapped (S's input = T's output gradient, S's
+// output gradient = T's input), flip-transposed:
+//   dW_T[co][ky][kx][ci] = dW_S[ci][2-ky][2-kx][co].
+static dvsof_conv_desc_t adjoint_of_transposed(const dvsof_conv_desc_t *d, int Ctot, const float *gy)
+{
+    dvsof_conv_desc_t a = *d;
+    a.nsrc = 1;
+    a.src[0].p = gy;
+    a.src[0].C = d->Cout;
+    a.src[0].layout = DVSOF_NHWC;
+    a.src[0].p16 = nullptr;
+    a.H = 2 * d->H;
+    a.W = 2 * d->W;
+    a.upsample = 0;
+    a.stride = 2;
+    a.Cout = Ctot;
+    a.scratch = nullptr;
+    a.scratch_bytes = 0;
+    a.winograd_input = nullptr;
+    return a;
+}
+static int channel_sum_blocks(long long npix, int C)
+{
+    const long long per = 256 / C, want = (npix + per * 8 - 1) / (per * 8);
+    return (int)(want < 1 ? 1 : want > 1024 ? 1024 : want);
+}
+
 size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
+    if (is_transposed(d)) {
+        static const float dummy = 0.f;
+        const dvsof_conv_desc_t a = adjoint_of_transposed(d, Ctot, &dummy);
+        size_t n = dvsof_conv2d_wgrad_workspace_bytes(&a);
+        n = (n + 255) & ~(size_t)255;
+        n += (size_t)Ctot * 9 * d->Cout * sizeof(float);                       // dW of the adjoint
+        if (d->Cout <= 256)
+            n += (size_t)channel_sum_blocks((long long)d->B * Ho * Wo, d->Cout) * d->Cout * sizeof(float);
+        return n + 256;
+    }
     if (is_wino_wgrad(d)) return wino_wgrad_workspace_floats(d->B, d->H, d->W, Ctot, d->Cout, d->mfma == 2 ? 2 : 0) * sizeof(float) + 16;
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
@@ -693,6 +834,32 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo) || !gout || !dweight) return DVSOF_EINVAL;
+    if (is_transposed(d)) {
+        if (dbias && d->Cout > 256) return DVSOF_EINVAL;
+        const dvsof_conv_desc_t a = adjoint_of_transposed(d, Ctot, gout);
+        size_t wsa = dvsof_conv2d_wgrad_workspace_bytes(&a);
+        wsa = (wsa + 255) & ~(size_t)255;
+        const size_t need = dvsof_conv2d_wgrad_workspace_bytes(d);
+        if (!ws || ws_bytes < need) return DVSOF_ENOSPACE;
+        float *dw_adj = (float *)((char *)ws + wsa);
+        float *part = dw_adj + (size_t)Ctot * 9 * d->Cout;
+        int rc = dvsof_conv2d_wgrad(&a, d->src[0].p, dw_adj, nullptr, ws, wsa, stream);
+        if (rc) return rc;
+        // [Ctot][tap][Cout] -> [Cout][8 - tap][Ctot]
+        rc = flip_transpose16(dw_adj, dweight, Ctot, 3, d->Cout, nullptr, nullptr, stream);
+        if (rc) return rc;
+        if (dbias) {
+            const long long npix = (long long)d->B * Ho * Wo;
+            const int nb = channel_sum_blocks(npix, d->Cout);
+            hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), gout,
+                               npix, d->Cout, part);
+            DVSOF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(channel_sum_final_kernel, dim3((d->Cout + 3) / 4), dim3(256), 0,
+                               as_stream(stream), (const float *)part, nb, d->Cout, dbias);
+            DVSOF_LAUNCH_CHECK();
+        }
+        return DVSOF_OK;
+    }
     if (is_wino_wgrad(d))
     {
         // the forward's transformed input, when the caller kept it and both use the same form
@@ -719,7 +886,7 @@ size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *d)
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return 0;
     if (is_wino(d)) return (size_t)d->Cout * Ctot * wino_components(d->B, d->H, d->W, d->mfma == 2 ? 2 : 0);
-    return (size_t)d->Cout * Ctot * (is_subpixel(d) ? 16 : d->ksize * d->ksize);
+    return (size_t)d->Cout * Ctot * ((is_subpixel(d) || is_transposed(d)) ? 16 : d->ksize * d->ksize);
 }
 
 size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *d)
@@ -768,6 +935,17 @@ int dvsof_conv2d_prepare16(const dvsof_conv_desc_t *d, const float *weight, floa
                                (const float *)w_fwd, w_dgrad, d->Cout, Ctot, w_dgrad16);
             DVSOF_LAUNCH_CHECK();
         }
+        return DVSOF_OK;
+    }
+    if (is_transposed(d)) {   // phase kernels forward, flip-transpose backward
+        if (!weight || (!w_fwd && !w_dgrad) || w_fwd == weight) return DVSOF_EINVAL;
+        if (w_fwd) {
+            const size_t n = (size_t)d->Cout * Ctot;
+            hipLaunchKernelGGL(transposed_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)),
+                               dim3(256), 0, st, weight, w_fwd, d->Cout, Ctot, w_fwd16);
+            DVSOF_LAUNCH_CHECK();
+        }
+        if (w_dgrad) return flip_transpose16(weight, w_dgrad, d->Cout, 3, Ctot, w_dgrad16, nullptr, stream);
         return DVSOF_OK;
     }
     if (is_wino(d)) {   // either form (or both) from the raw weights

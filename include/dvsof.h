@@ -266,14 +266,29 @@ typedef struct {
  * the input is the channel concatenation of nsrc tensors of spatial size
  * H x W, optionally 2x nearest-upsampled first; ksize x ksize taps, zero
  * padding `pad`, stride 1 or 2.  Output is NHWC [B,Ho,Wo,Cout] with
- * Ho = (H*(1+upsample) + 2*pad - ksize)/stride + 1.
+ * Ho = (H*(upsample ? 2 : 1) + 2*pad - ksize)/stride + 1.
  * Weights are [Cout][ksize][ksize][Ctot] (channels contiguous, Ctot = sum C).
+ *
+ * upsample = 2 makes the layer a TRANSPOSED convolution with stride 2 (the
+ * north star's "strided conv / transposed-conv / Mish stack"; the reference's
+ * network source is absent, docs/MODEL_SPEC.md keeps nearest up-sampling as
+ * the decoder's default): zeros are inserted between the input pixels
+ * (xz[2i][2j] = x[i][j]) before the 3x3 / pad-1 convolution, Ho = 2H.  With
+ * W' = W flipped in both tap axes and its channel axes swapped this is
+ * torch conv_transpose2d(x, W', stride 2, padding 1, output_padding 1).
+ * Forward: four output-parity phases of (1+py)(1+px) taps on the
+ * low-resolution input (prepared form [4][Cout][2][2][Ctot]); data gradient:
+ * a stride-2 3x3 convolution of the output gradient with the flip-transposed
+ * weights; weight gradient: that of the adjoint stride-2 layer, flip-
+ * transposed; bias gradient: channel sums of the output gradient.
  */
 typedef struct {
     dvsof_src_t src[3];
     int nsrc;
     int B, H, W;
-    int upsample; /* 0 | 1 */
+    int upsample; /* 0 | 1 = 2x nearest | 2 = 2x zero insertion (transposed
+                     convolution, stride 2: one NHWC source with C % 16 == 0,
+                     ksize 3, pad 1, stride 1; see below) */
     int ksize, stride, pad;
     int Cout;
     int act; /* DVSOF_ACT_* */

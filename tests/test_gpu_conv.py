@@ -151,6 +151,68 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     close(db, b.grad)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,act', [
+    (2, 8, 12, 32, 64, 'relu'),
+    (1, 5, 7, 64, 48, 'mish'),        # odd sizes, Cout not a tile multiple
+    (8, 32, 32, 128, 64, 'relu'),     # a decoder-stage shape
+])
+def test_transposed_conv_layer(B, H, W, Cin, Cout, act):
+    """upsample = UP_ZERO: 2x zero insertion + 3x3/pad 1 = transposed
+    convolution with stride 2 (north star: "strided conv / transposed-conv /
+    Mish stack"), run as four output-parity phases on the matrix cores.
+    Forward, data gradient (a stride-2 convolution of the output gradient) and
+    weight / bias gradient (the adjoint stride-2 layer's, flip-transposed)
+    against ATen on the zero-inserted input and against conv_transpose2d."""
+    from dvs_of_training_framework_amd import conv as C
+    g = torch.Generator().manual_seed(B * 100 + H)
+    a = {'relu': C.ACT_RELU, 'mish': C.ACT_MISH}[act]
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    xw = torch.stack([x, torch.zeros_like(x)], dim=-1).reshape(B, Cin, H, 2 * W)
+    xz = torch.stack([xw, torch.zeros_like(xw)], dim=-2).reshape(B, Cin, 2 * H, 2 * W)
+    assert torch.equal(xz[:, :, ::2, ::2], x) and int((xz != 0).sum()) == int((x != 0).sum())
+    z_ref = F.conv2d(xz, w, b, padding=1)
+    z_t = F.conv_transpose2d(x, w.flip(2, 3).transpose(0, 1), b, stride=2, padding=1,
+                             output_padding=1)
+    close(z_t, z_ref, 1e-5)       # the layer IS conv_transpose2d (flipped kernel)
+    y_ref = F.relu(z_ref) if act == 'relu' else F.mish(z_ref)
+    x_d = nhwc(x.detach())
+    desc = C.make_desc([(x_d, Cin, C.NHWC)], B, H, W, Cout, 3, 1, 1, C.UP_ZERO, a)
+    assert C.out_size(desc) == (2 * H, 2 * W)
+    w_fwd, w_dg = C.prepare(desc, wphys(w.detach()), True)
+    assert w_fwd.numel() == 16 * Cout * Cin and w_dg.numel() == 9 * Cout * Cin
+    y, z = C.conv_fwd(desc, w_fwd, b.detach().cuda(), 'cuda', None, want_z=True)
+    close(from_nhwc(z), z_ref)
+    close(from_nhwc(y), y_ref)
+    gz = torch.randn(z_ref.shape, generator=g)
+    z_ref.backward(gz)
+    gz_d = nhwc(gz)
+    gx = torch.empty(B, H, W, Cin, device='cuda')
+    C.conv_dgrad(desc, w_dg, gz_d, [dict(p=gx)])
+    close(from_nhwc(gx), x.grad)
+    dw = torch.empty(Cout, 3, 3, Cin, device='cuda')
+    db = torch.empty(Cout, device='cuda')
+    C.conv_wgrad(desc, gz_d, dw, db)
+    close(dw.permute(0, 3, 1, 2), w.grad)
+    close(db, b.grad)
+
+
+def test_transposed_conv_rejects_what_it_does_not_implement():
+    from dvs_of_training_framework_amd import conv as C
+    x = torch.zeros(1, 4, 4, 32, device='cuda')
+    for bad in (dict(ksize=5, pad=2), dict(stride=2)):
+        kw = dict(ksize=3, stride=1, pad=1)
+        kw.update(bad)
+        d = C.make_desc([(x, 32, C.NHWC)], 1, 4, 4, 32, upsample=C.UP_ZERO, **kw)
+        with pytest.raises(RuntimeError):
+            C.conv_fwd(d, torch.zeros(32 * 16 * 32, device='cuda'), None, 'cuda')
+    x5 = torch.zeros(1, 5, 4, 4, device='cuda')      # planar 5-channel source
+    d = C.make_desc([(x5, 5, C.NCHW)], 1, 4, 4, 32, upsample=C.UP_ZERO)
+    with pytest.raises(RuntimeError):
+        C.conv_fwd(d, torch.zeros(32 * 16 * 5, device='cuda'), None, 'cuda')
+
+
 @pytest.mark.parametrize('case', [
     dict(B=2, H=8, W=8, src=[(32, 'nhwc')], Cout=64, stride=2),
     dict(B=8, H=16, W=8, src=[(256, 'nhwc')], Cout=256, stride=1),     # Winograd F(4x4,3x3)
