@@ -265,7 +265,10 @@ def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE, weight16=None,
         bwd_act, _lib.stream()), 'dvsof_conv2d_dgrad')
 
 
-def conv_wgrad(desc, gout, dweight, dbias):
+def conv_wgrad(desc, gout, dweight, dbias, gout16=None):
+    """gout16: bf16 twin of gout (mode 3): with the sources' twins the
+    vector members' weight gradient streams bf16 through LDS."""
+    desc.gout16 = _lib.ptr(gout16)
     nbytes = _plan(desc)[4]
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32,
                      device=gout.device)

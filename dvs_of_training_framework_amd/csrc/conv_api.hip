@@ -510,7 +510,18 @@ void fill_wgrad(const dvsof_conv_desc_t *d, int Ctot, int Ho, int Wo, WGradParam
     const int up = d->upsample ? 2 : 1;
     P.nsrc = d->nsrc;
     for (int i = 0; i < d->nsrc; ++i)
-        P.src[i] = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);
+        P.src[i] = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W,
+                            d->mfma == 3 ? d->src[i].p16 : nullptr);
+    // bf16 twins (mode 3): gout and every vector member streamed from their bf16
+    // copies when all of them exist and channel runs are whole 16-byte loads
+    P.gout16 = d->mfma == 3 ? (const unsigned short *)d->gout16 : nullptr;
+    P.twins = P.gout16 != nullptr && (d->Cout % 8) == 0;
+    {
+        static const bool off = getenv("DVSOF_WGRAD_NO_TWINS") != nullptr;
+        if (off) P.twins = 0;
+    }
+    for (int i = 0; i < d->nsrc; ++i)
+        if (!P.src[i].flat && (!P.src[i].p16 || (P.src[i].C % 8))) P.twins = 0;
     P.B = d->B;
     P.Hv = d->H * up;
     P.Wv = d->W * up;

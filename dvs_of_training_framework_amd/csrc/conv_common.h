@@ -92,6 +92,8 @@ struct WGradParams {
     int nph, ph_pad, S;   // phases (1|4), pad shift per phase, K splits
     int mfma_bf16;        // as in GConvParams
     long long src_ph_stride;   // elements between the source planes of two phases (winograd.hip)
+    const unsigned short *gout16;   // bf16 twin of gout (mfma mode 3) or null
+    int twins;            // 1: the vector members and gout are read from their bf16 twins (wgrad2_twins_kernel)
 };
 
 // Weight gradient of one flat concat member on the VALU (wgrad.hip), in the

@@ -301,6 +301,280 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// bf16 TWINS form (mfma mode 3): gout and the vector members are read from
+// their bf16 copies, [pixel][channel] in memory like the f32 tensors.  A stage
+// is 32 pixels (two 16-pixel groups, each with its own scalar base offset), so
+// the 1 KiB LDS-DMA pieces, their count and the ring are those of the f32
+// kernel at half the bytes per pixel.  K = pixels is the SLOW axis of the LDS
+// image [pixel][channel]; the 8 consecutive k a lane feeds to one
+// v_mfma_f32_32x32x16_bf16 come from two ds_read_b64_tr_b16: per 16-lane group
+// a block of 4 pixels x 16 channels, delivered channel-major (lane i <- channel
+// i, elements = the 4 pixels).  A and B use the same (lane, element) -> k map.
+// Bank conflicts: the 4 pixel rows of a block are one row pitch apart -- 256 B
+// (128-wide operand: all 4 on the same banks) or 128 B (64-wide: rows q, q+2
+// collide).  An LDS-DMA writes lane-linear 1 KiB pieces, so the image cannot be
+// padded; instead a lane FETCHES a permuted channel chunk: the 64-byte group G
+// of row r holds channel group G ^ f(r), f = r & 3 (256-B rows) | (r >> 1) & 1
+// (128-B rows) | 0 (64-B rows), and the fragment reads apply the same XOR.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int w2t_swz(int chunks_per_row, int row)
+{
+    return chunks_per_row >= 16 ? (row & 3) : chunks_per_row == 8 ? ((row >> 1) & 1) : 0;
+}
+template <int WROWS, int WCOLS, int TM, int TN>
+__global__ __launch_bounds__(CONV_NT) void wgrad2_twins_kernel(const WGradParams P)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    constexpr int KP = 32;                          // pixels per stage
+    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    constexpr int PA0 = BMc / 16, PB = BN / 16;     // 1 KiB pieces per stage (KP * rows * 2 B / 1024)
+    constexpr int PA = PA0 + ((4 - (PA0 + PB) % 4) % 4);
+    constexpr int LPW = (PA + PB) / 4;
+    constexpr int STAGE = (PA + PB) * 1024;
+    constexpr int RPA = 512 / BMc, RPB = 512 / BN;  // pixel rows per piece (divide 16)
+    static_assert(WROWS * WCOLS == CONV_NT / kWave, "4 waves");
+    static_assert(16 % RPA == 0 && 16 % RPB == 0, "a piece lies in one 16-pixel group");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int taps = P.ks * P.ks;
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int s = 0;
+    for (int i = 1; i < P.nsrc; ++i)
+        if (bx >= P.tile_begin[i]) s = i;
+    const GSrc &S = P.src[s];
+    int coff = 0;
+    for (int i = 0; i < s; ++i) coff += P.src[i].C;
+    const int f0 = (bx - P.tile_begin[s]) * BN;
+    const int fmax = taps * S.C;
+    const int co0 = by * BMc;
+    const int ph = bz / P.S, split = bz - ph * P.S;
+    const int phy = ph >> 1, phx = ph & 1;
+    const int pad_y = P.pad - phy * P.ph_pad, pad_x = P.pad - phx * P.ph_pad;
+    const int kbeg = split * P.klen;
+    const int kend = min(P.M, kbeg + P.klen);
+    int groups_left = (kend - kbeg + BK - 1) / BK;          // 16-pixel groups of this K split
+    const int nsteps = (groups_left + 1) / 2;
+
+    const int Hv = P.Hv, Wv = P.Wv, Wo = P.Wo, Ho = P.Ho, stride = P.stride;
+    const int s_sy = S.sy, s_sx = S.sx;
+    const long long s_sb = S.sb, g_sb = P.g_sb;
+    const int g_sy = P.g_sy, g_sx = P.g_sx;
+
+    // load slots: piece p = wave + 4*i; a lane fetches 16 B = 8 channels of pixel
+    // jj of 16-pixel group gi of the stage
+    unsigned c_voff[LPW];
+    int b_cy[LPW], b_cx[LPW];
+    bool b_ok[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int p = wave + 4 * i;
+        c_voff[i] = WOOB;
+        b_cy[i] = b_cx[i] = 0;
+        b_ok[i] = false;
+        if (p < PA) {
+            const int r = p * RPA + (lane * 8) / BMc, jj = r & 15, slot = ((lane * 8) % BMc) >> 3;
+            const int col = ((((slot >> 2) ^ w2t_swz(BMc / 8, r)) << 2) | (slot & 3)) * 8;
+            if (p < PA0 && co0 + col < P.Cout)
+                c_voff[i] = (unsigned)((jj * g_sx + co0 + col) * 2);
+        } else {
+            const int q = p - PA;
+            const int r = q * RPB + (lane * 8) / BN, jj = r & 15, slot = ((lane * 8) % BN) >> 3;
+            const int col = ((((slot >> 2) ^ w2t_swz(BN / 8, r)) << 2) | (slot & 3)) * 8;
+            const int f = f0 + col;
+            b_ok[i] = f < fmax;
+            const int tap = b_ok[i] ? f / S.C : 0, c = f - tap * S.C;
+            const int ky = tap / P.ks, kx = tap - ky * P.ks;
+            b_cy[i] = ky - pad_y;
+            b_cx[i] = jj * stride + kx - pad_x;
+            c_voff[i] = (unsigned)((ky * s_sy + (jj * stride + kx) * s_sx + c) * 2);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t gres =
+        __builtin_amdgcn_make_buffer_rsrc((void *)P.gout16, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(S.p16 + (long long)ph * P.src_ph_stride - ((long long)pad_y * s_sy + (long long)pad_x * s_sx)), 0,
+        0x7fffffff, 0x00020000);
+    const long long g_ph = (long long)phy * P.g_py + (long long)phx * P.g_px;
+
+    int g_ox = kbeg % Wo, g_oy = (kbeg / Wo) % Ho, g_b = kbeg / (Wo * Ho);
+    int a_row = 0, b_row = 0;
+    auto row_bases = [&]() {
+        a_row = (int)(((long long)g_b * g_sb + (long long)g_oy * g_sy + g_ph) * 2);
+        b_row = (int)(((long long)g_b * s_sb + (long long)(g_oy * stride) * s_sy) * 2);
+    };
+    row_bases();
+    const int a_px = g_sx * 2, b_px = stride * s_sx * 2;
+
+    auto issue = [&](int stage_idx) {
+        // the two 16-pixel groups of the stage (the second may lie past the K split)
+        int a_so0, a_so1, b_so0, b_so1, gy0, gy1, gx0, gx1;
+        bool live0, live1;
+        auto next_group = [&](int &a_so, int &b_so, int &gy, int &gx, bool &live) {
+            live = groups_left > 0;
+            a_so = __builtin_amdgcn_readfirstlane(a_row + g_ox * a_px);
+            b_so = __builtin_amdgcn_readfirstlane(b_row + g_ox * b_px);
+            gy = g_oy * stride;
+            gx = g_ox * stride;
+            if (live) {
+                --groups_left;
+                g_ox += BK;
+                if (g_ox >= Wo) {
+                    g_ox = 0;
+                    if (++g_oy == Ho) {
+                        g_oy = 0;
+                        ++g_b;
+                    }
+                    row_bases();
+                }
+            }
+        };
+        next_group(a_so0, b_so0, gy0, gx0, live0);
+        next_group(a_so1, b_so1, gy1, gx1, live1);
+        unsigned char *st = smem + stage_idx * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int p = wave + 4 * i;
+            __attribute__((address_space(3))) void *dst =
+                (__attribute__((address_space(3))) void *)(st + p * 1024);
+            if (p < PA) {
+                const bool g1 = ((p * RPA) >> 4) != 0;      // scalar: second group of the stage
+                const bool live = g1 ? live1 : live0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, live ? c_voff[i] : WOOB,
+                                                         g1 ? a_so1 : a_so0, 0, 0);
+            } else {
+                const bool g1 = (((p - PA) * RPB) >> 4) != 0;
+                const int gy = g1 ? gy1 : gy0, gx = g1 ? gx1 : gx0;
+                const bool ok = (g1 ? live1 : live0) & b_ok[i] & ((unsigned)(gy + b_cy[i]) < (unsigned)Hv) &
+                                ((unsigned)(gx + b_cx[i]) < (unsigned)Wv);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sres, dst, 16, ok ? c_voff[i] : WOOB,
+                                                         g1 ? b_so1 : b_so0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    const bool do_bias = P.dbias != nullptr && bx == 0 && wc == 0;
+    float bsum[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) bsum[t] = 0.f;
+    // transposed fragment reads: group g = lane >> 4 covers channels 16 (g & 1) ..
+    // and pixels 8 (g >> 1) + 4 rd .. of a 16-pixel slice; lane 4q + p of the group
+    // addresses pixel row q, channels 4p .. 4p + 3
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    // byte offset inside a stage of (pixel row 8 (tg >> 1) + tq, 32-channel tile T):
+    // row pitch + swizzled 64-byte group + position inside the group
+    const int in_group = (2 * (tg & 1) + (tp >> 1)) * 16 + (tp & 1) * 8;
+    int a_lane[TM], b_lane[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+        a_lane[t] = (8 * (tg >> 1) + tq) * BMc * 2 + (((wr * TM + t) ^ w2t_swz(BMc / 8, tq)) << 6) + in_group;
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+        b_lane[t] = PA * 1024 + (8 * (tg >> 1) + tq) * BN * 2 +
+                    (((wc * TN + t) ^ w2t_swz(BN / 8, tq)) << 6) + in_group;
+
+    auto compute = [&](int u) {
+        const unsigned char *st = smem + u * STAGE;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {        // the two 16-pixel slices of the stage
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const unsigned char *a0 = st + a_lane[t] + 16 * sl * BMc * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)a0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(a0 + 4 * BMc * 2));
+                fa[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const unsigned char *b0 = st + b_lane[t] + 16 * sl * BN * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)b0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(b0 + 4 * BN * 2));
+                fb[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    const s16x8 v = __builtin_bit_cast(s16x8, fa[t]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        bsum[t] += __builtin_bit_cast(float, (unsigned)(unsigned short)v[e] << 16);
+                }
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int u = 0; u < WNS - 1; ++u)
+        if (u < nsteps) issue(u);
+    static_assert(WNS == 4, "ring of 4 stages");
+    for (int s0 = 0; s0 < nsteps; s0 += WNS) {
+#pragma unroll
+        for (int u = 0; u < WNS; ++u) {
+            const int st = s0 + u;
+            if (st < nsteps) {
+                if (st + WNS - 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WNS - 2) * LPW) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                if (st + WNS - 1 < nsteps) issue((u + WNS - 1) % WNS);
+                compute(u);
+            }
+        }
+    }
+
+    if (do_bias) {   // lanes l and l^32 hold the two k halves of the same channel
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32);
+            const int co = co0 + (wr * TM + t) * 32 + lrow;
+            if (lh == 0 && co < P.Cout) P.dbias[(size_t)bz * P.Cout + co] = v;
+        }
+    }
+    const size_t wsize = (size_t)P.Cout * taps * P.Cin_tot;
+    float *dW = P.dW + (size_t)bz * wsize;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int f = f0 + (wc * TN + tn) * 32 + lrow;
+        if (f >= fmax) continue;
+        const int tap = f / S.C, c = f - tap * S.C;
+        const size_t col = (size_t)tap * P.Cin_tot + coff + c;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + (wr * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (co < P.Cout) dW[(size_t)co * taps * P.Cin_tot + col] = acc[tm][tn][reg];
+            }
+    }
+#endif
+}
+
 namespace {
 
 template <int WROWS, int WCOLS, int TM, int TN, int BF16, int TAG = 0>
@@ -322,8 +596,27 @@ int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
 }
 
 template <int WROWS, int WCOLS, int TM, int TN>
+int launch_w2t(const WGradParams &P, int ntiles, hipStream_t st)
+{
+    constexpr int BMc = WROWS * TM * 32, BN = WCOLS * TN * 32;
+    constexpr int PA0 = BMc / 16, PB = BN / 16, PA = PA0 + ((4 - (PA0 + PB) % 4) % 4);
+    constexpr size_t LDS = (size_t)WNS * (PA + PB) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad2_twins_kernel<WROWS, WCOLS, TM, TN>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_set = true;
+    }
+    dim3 grid(ntiles, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
+    hipLaunchKernelGGL((wgrad2_twins_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), LDS, st, P);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+template <int WROWS, int WCOLS, int TM, int TN>
 int launch_w2(const WGradParams &P, int ntiles, hipStream_t st)
 {
+    if (P.twins) return launch_w2t<WROWS, WCOLS, TM, TN>(P, ntiles, st);
     if (P.mfma_bf16 == 2) return launch_w2x<WROWS, WCOLS, TM, TN, 2>(P, ntiles, st);
     if (P.mfma_bf16 == 1) return launch_w2x<WROWS, WCOLS, TM, TN, 1>(P, ntiles, st);
     return launch_w2x<WROWS, WCOLS, TM, TN, 0>(P, ntiles, st);

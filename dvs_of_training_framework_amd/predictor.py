@@ -275,9 +275,9 @@ class _PredictorFn(torch.autograd.Function):
         sides = [side] + (ctx.module._extra_streams(dev) if side is not None else [])
         turn = [0]
 
-        def wgrad(desc, gz, gw, gb, unit):
+        def wgrad(desc, gz, gw, gb, unit, gz16=None):
             if side is None:
-                C.conv_wgrad(desc, gz, gw, gb)
+                C.conv_wgrad(desc, gz, gw, gb, gz16)
                 finish(unit)
                 return
             s_ = sides[turn[0] % len(sides)]
@@ -286,9 +286,9 @@ class _PredictorFn(torch.autograd.Function):
             ready.record(main)
             s_.wait_event(ready)
             with torch.cuda.stream(s_):
-                C.conv_wgrad(desc, gz, gw, gb)
+                C.conv_wgrad(desc, gz, gw, gb, gz16)
                 finish(unit)
-            keep.append(gz)
+            keep.extend((gz, gz16))
 
         # ---- decoder, fine to coarse
         g_x = None          # gradient w.r.t. dec[i].y from the finer stage
@@ -304,7 +304,7 @@ class _PredictorFn(torch.autograd.Function):
             pw, pb, pfw, pfb = (po_dec + 4 * i + j for j in range(4))
             C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
                        grads[pfw], grads[pfb], B, h, w, d.Cout, gx16=gz16)
-            wgrad(d, gz, grads[pw], grads[pb], ('dec', i))
+            wgrad(d, gz, grads[pw], grads[pb], ('dec', i), gz16)
             srcs = lay['srcs']
             g_in = new(srcs[0][0])
             g_e = new(srcs[1][0])
@@ -330,12 +330,12 @@ class _PredictorFn(torch.autograd.Function):
         for i in reversed(range(NUM_RES)):
             l1, l2 = res_l[2 * i], res_l[2 * i + 1]
             pw1, pb1, pw2, pb2 = (po_res + 4 * i + j for j in range(4))
-            wgrad(l2['desc'], gs, grads[pw2], grads[pb2], ('res', i, 2))
+            wgrad(l2['desc'], gs, grads[pw2], grads[pb2], ('res', i, 2), gs16)
             g_t, g_t16 = new(l1['y']), tw(l1['y'])
             C.conv_dgrad(l2['desc'], wt(l2), gs,
                          [dict(p=g_t, actsrc=asrc(l1), p16=g_t16)], act,
                          weight16=l2['w_dg16'], gout16=gs16)
-            wgrad(l1['desc'], g_t, grads[pw1], grads[pb1], ('res', i, 1))
+            wgrad(l1['desc'], g_t, grads[pw1], grads[pb1], ('res', i, 1), g_t16)
             below = res_l[2 * i - 1] if i > 0 else enc_l[3]
             g_prev, g_prev16 = new(below['y']), tw(below['y'])
             dst = dict(p=g_prev, addend=gs, actsrc=asrc(below), p16=g_prev16)
@@ -354,7 +354,8 @@ class _PredictorFn(torch.autograd.Function):
         n_side = int(os.environ.get('DVSOF_ENC_SIDE_FROM', '2'))
         for i in (3, 2, 1, 0):
             lay = enc_l[i]
-            item = (lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i))
+            item = (lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i),
+                    gz16)
             if i >= n_side:
                 wgrad(*item)            # second stream (it is about to run dry)
             else:
@@ -369,11 +370,11 @@ class _PredictorFn(torch.autograd.Function):
                          weight16=lay['w_dg16'], gout16=gz16)
             keep.append(gz16)
             gz, gz16 = g_prev, g_prev16
-        for desc, g, gw, gb, unit in deferred:
+        for desc, g, gw, gb, unit, g16 in deferred:
             if side is None:
-                wgrad(desc, g, gw, gb, unit)
+                wgrad(desc, g, gw, gb, unit, g16)
             else:
-                C.conv_wgrad(desc, g, gw, gb)
+                C.conv_wgrad(desc, g, gw, gb, g16)
                 finish(unit)
         if side is not None:
             for s_ in sides:

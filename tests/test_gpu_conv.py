@@ -151,6 +151,50 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     close(db, b.grad)
 
 
+@pytest.mark.parametrize('case', [
+    dict(B=2, H=16, W=32, src=[(64, 'nhwc')], Cout=64, stride=1),
+    dict(B=3, H=16, W=16, src=[(32, 'nhwc')], Cout=128, stride=2),        # odd number of 16-pixel groups per split
+    dict(B=2, H=16, W=16, src=[(64, 'nhwc'), (32, 'nhwc'), (2, 'nchw')], Cout=32, up=True),   # sub-pixel phases + a flat member
+    dict(B=8, H=64, W=64, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),                # 32 x 128 tile, many K splits
+    dict(B=4, H=16, W=16, src=[(256, 'nhwc')], Cout=256, stride=1),                          # direct wide layer (no Winograd in mode 3)
+])
+def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
+    """mfma mode 3: the vector members' weight gradient streams the bf16 TWINS
+    of gout and of the sources through LDS (ds_read_b64_tr_b16 transposed
+    fragment reads, K = pixels).  Mode 1 rounds the same f32 values to bf16 in
+    registers, so both multiply identical operands: equal up to f32 summation
+    order.  Bias gradient: sums of the bf16-rounded gout (2^-9 per element)."""
+    C, xs, w, b, desc, act, o = build(case, seed=11)
+    ho, wo = C.out_size(desc)
+    g = torch.Generator().manual_seed(5)
+    gz = torch.randn(case['B'], case['Cout'], ho, wo, generator=g)
+    gz_d = nhwc(gz)
+    ctot = sum(c for c, _ in case['src'])
+
+    def run(mode, twins):
+        srcs = []
+        for t, (c, lay) in zip(desc._keepalive, case['src']):
+            t16 = t.to(torch.bfloat16) if (twins and lay == 'nhwc') else None
+            srcs.append((t, c, C.NCHW if lay == 'nchw' else C.NHWC, t16))
+        d = C.make_desc(srcs, case['B'], case['H'], case['W'], case['Cout'], o['k'], o['stride'],
+                        o['pad'], o['up'], act, mode)
+        d._keep = srcs
+        dw = torch.empty(case['Cout'], o['k'], o['k'], ctot, device='cuda')
+        db = torch.empty(case['Cout'], device='cuda')
+        C.conv_wgrad(d, gz_d, dw, db, gz_d.to(torch.bfloat16) if twins else None)
+        torch.cuda.synchronize()
+        return dw, db
+    dw1, db1 = run(C.MFMA_BF16, False)
+    dw3, db3 = run(C.MFMA_BF16_TWINS, True)
+    close(dw3, dw1, 1e-5)
+    close(db3, db1, 1e-2)
+    dw3b, _ = run(C.MFMA_BF16_TWINS, True)
+    assert torch.equal(dw3, dw3b)                 # fixed-order reductions
+    # and both stay within the bf16 bound of the exact gradient
+    dwx, _ = run(C.MFMA_F32, False)
+    close(dw3, dwx, BF16_RTOL)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout,act', [
     (2, 8, 12, 32, 64, 'relu'),
     (1, 5, 7, 64, 48, 'mish'),        # odd sizes, Cout not a tile multiple
