@@ -271,6 +271,8 @@ def measure_roofline(h, step_ms, steps=3):
             return out
         return inner
 
+    last_call = {}
+
     def timed(fn, key):
         def inner(*args, **kw):
             e0, e1 = pair()
@@ -278,8 +280,31 @@ def measure_roofline(h, step_ms, steps=3):
             out = fn(*args, **kw)
             e1.record()
             hbm_rec[key].append((e0, e1))
+            last_call[key] = (fn, args, kw)
             return out
         return inner
+
+    def alone(key, reps=20):
+        """The same call path with the GPU to itself (the in-situ figure shares
+        the GPU with the other lane's kernels): seconds per call."""
+        if key not in last_call:
+            return 0.0
+        fn, args, kw = last_call[key]
+        with torch.no_grad():
+            for _ in range(3):
+                fn(*args, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = pair()
+            # behind a ~10 ms spin kernel: the host runs ahead and the events
+            # bracket back-to-back device work (these paths are shorter than
+            # their enqueue from Python)
+            torch.cuda._sleep(25_000_000)
+            e0.record()
+            for _ in range(reps):
+                fn(*args, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
 
     def collect():
         del records[:]
@@ -308,6 +333,7 @@ def measure_roofline(h, step_ms, steps=3):
                for k, v in hbm_rec.items()}
         return out, hbm
     agg, hbm_t = collect()      # as timed: two backward streams, launches overlap
+    hbm_alone = {k: alone(k) for k in hbm_rec}
     # the same launches one at a time (second backward stream off): what a kernel
     # does when it has the GPU to itself
     prev = os.environ.get('DVSOF_WGRAD_STREAM')
@@ -342,6 +368,11 @@ def measure_roofline(h, step_ms, steps=3):
                         'call_path_us': round(t * 1e6, 2),
                         'achieved': round(nbytes / t / 1e9, 1), 'peak': PEAK_HBM_TBS * 1e3,
                         'unit': 'GB/s', 'frac': round(nbytes / t / 1e12 / PEAK_HBM_TBS, 4)}
+            ta = hbm_alone.get(key, 0.0)
+            if ta > 0:      # the same call path back to back with nothing else on the GPU
+                hbm[key]['alone'] = {'call_path_us': round(ta * 1e6, 2),
+                                     'achieved': round(nbytes / ta / 1e9, 1),
+                                     'frac': round(nbytes / ta / 1e12 / PEAK_HBM_TBS, 4)}
     roof = {
         # dominant kernel group: FLOPs the matrix cores EXECUTE per launch (the
         # sub-pixel / phase / Winograd forms issue fewer than the layer's
