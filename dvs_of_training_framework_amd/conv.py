@@ -26,7 +26,7 @@ class ConvDesc(ctypes.Structure):
                 ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i),
                 ('scratch', _vp), ('scratch_bytes', _sz),
                 ('winograd_input', _vp), ('y16', _vp), ('w16', _vp),
-                ('gout16', _vp)]
+                ('gout16', _vp), ('flags', _i)]
 
 
 class GradDst(ctypes.Structure):
@@ -60,6 +60,11 @@ _lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])
 _lib.register('dvsof_conv2d_prepare16', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp])
 _lib.register('dvsof_to_bf16_many', _i, [_P(_vp), _P(_vp), _P(ctypes.c_size_t), _i, _vp])
 _lib.register('dvsof_conv2d_scratch_bytes', _sz, [_P(ConvDesc)])
+_lib.register('dvsof_flow_fold_weights', _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
+_lib.register('dvsof_flow_fold_workspace_bytes', _sz, [_i, _i])
+_lib.register('dvsof_flow_fold_grads', _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp,
+                                            _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp])
+WGRAD_SKIP_FLAT = 1
 _lib.register('dvsof_conv2d_winograd_tile', _i, [_P(ConvDesc), _i])
 
 
@@ -265,10 +270,34 @@ def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE, weight16=None,
         bwd_act, _lib.stream()), 'dvsof_conv2d_dgrad')
 
 
-def conv_wgrad(desc, gout, dweight, dbias, gout16=None):
+def flow_fold_weights(w, Cout, Ctot, cx_off, Cx, cf_off, wh):
+    """-> w_eff [Cout][9][Ctot-2] (dvsof_flow_fold_weights)."""
+    out = torch.empty(Cout * 9 * (Ctot - 2), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().dvsof_flow_fold_weights(
+        w.data_ptr(), Cout, Ctot, cx_off, Cx, cf_off, wh.data_ptr(),
+        out.data_ptr(), _lib.stream()), 'dvsof_flow_fold_weights')
+    return out
+
+
+def flow_fold_grads(dW, w, Cout, Ctot, cx_off, Cx, cf_off, wh, bh, db_conv, g,
+                    B, H, W, dwh, dbh):
+    """Flow columns of dW and the head's gradient additions
+    (dvsof_flow_fold_grads)."""
+    n = _lib.lib().dvsof_flow_fold_workspace_bytes(B, Cout)
+    ws = torch.empty(n // 4 + 1, dtype=torch.float32, device=g.device)
+    _lib.check(_lib.lib().dvsof_flow_fold_grads(
+        dW.data_ptr(), w.data_ptr(), Cout, Ctot, cx_off, Cx, cf_off,
+        wh.data_ptr(), bh.data_ptr(), db_conv.data_ptr(), g.data_ptr(), B, H,
+        W, dwh.data_ptr(), dbh.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+        _lib.stream()), 'dvsof_flow_fold_grads')
+
+
+def conv_wgrad(desc, gout, dweight, dbias, gout16=None, skip_flat=False):
     """gout16: bf16 twin of gout (mode 3): with the sources' twins the
-    vector members' weight gradient streams bf16 through LDS."""
+    vector members' weight gradient streams bf16 through LDS.  skip_flat:
+    the narrow planar members' columns are left to flow_fold_grads."""
     desc.gout16 = _lib.ptr(gout16)
+    desc.flags = WGRAD_SKIP_FLAT if skip_flat else 0
     nbytes = _plan(desc)[4]
     ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32,
                      device=gout.device)

@@ -885,7 +885,9 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
     fill_wgrad(d, Ctot, Ho, Wo, P);
     P.gout = gout;
     FlatWG F[3];
-    const int nflat = fill_flat(d, Ctot, Ho, Wo, gout, F);
+    // DVSOF_CONV_WGRAD_SKIP_FLAT: the flat members' columns are the caller's
+    // (dvsof_flow_fold_grads); the vector members' columns are written as usual
+    const int nflat = (d->flags & DVSOF_CONV_WGRAD_SKIP_FLAT) ? 0 : fill_flat(d, Ctot, Ho, Wo, gout, F);
     if (wgrad_workspace_floats(P, dbias != nullptr) + wgrad_flat_workspace_floats(F, nflat) > 0 && !ws)
         return DVSOF_ENOSPACE;
     return wgrad_launch(P, dweight, dbias, (float *)ws, ws_bytes / sizeof(float), F, nflat,

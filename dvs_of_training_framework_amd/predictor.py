@@ -153,10 +153,15 @@ class _PredictorFn(torch.autograd.Function):
             raw16 = {id(w_): t_ for w_, t_ in
                      zip(raws, C.to_bf16_many([_phys(w_) for w_ in raws]))}
 
+        fold_on = want_grad and os.environ.get('DVSOF_FLOW_FOLD', '1') != '0' and \
+            len(module._extra_streams(dev)) == 0
+
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
-                residual=None):
+                residual=None, head=None):
             """-> (y, y16): the layer's output and, in the bf16-twins mode,
-            its bf16 copy (written by the same kernel)."""
+            its bf16 copy (written by the same kernel).  head = (Wh, bh) of
+            the flow head whose output is the layer's third member: the
+            backward folds that member into weight space (csrc/flowfold.hip)."""
             d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act,
                             module.mfma)
             # prepared weights: sub-pixel phase kernels for the decoder,
@@ -164,7 +169,7 @@ class _PredictorFn(torch.autograd.Function):
             # data-gradient form, made once per step
             first = len(L) == 0       # voxel input needs no data gradient
             need_dg = want_grad and not first
-            w_fwd16 = w_dg16 = None
+            w_fwd16 = w_dg16 = w_dg = fold = None
             if side is not None and need_dg:
                 if len(L) in pre:             # made on the second stream
                     w_fwd, w_fwd16 = pre[len(L)]
@@ -178,12 +183,18 @@ class _PredictorFn(torch.autograd.Function):
                         ev.record(main)
                         side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    _, w_dg, _, w_dg16 = _prep(d, _phys(wgt), True,
+                    if head is not None and fold_on:
+                        fold = _fold_forms(srcs, h, w, cout, wgt, head)
+                    else:
+                        _, w_dg, _, w_dg16 = _prep(d, _phys(wgt), True,
                                                    phase_weights=w_fwd,
                                                    want16=twins)
             else:
+                folded = head is not None and fold_on and need_dg
                 w_fwd, w_dg, w_fwd16, w_dg16 = _prep(
-                    d, _phys(wgt), need_dg, want16=twins)
+                    d, _phys(wgt), need_dg and not folded, want16=twins)
+                if folded:
+                    fold = _fold_forms(srcs, h, w, cout, wgt, head)
             if twins and w_fwd16 is None:
                 w_fwd16 = raw16.get(id(wgt))
                 if w_fwd16 is None or w_fwd is not wgt:
@@ -192,8 +203,21 @@ class _PredictorFn(torch.autograd.Function):
                               keep_input_transform=want_grad,
                               weight16=w_fwd16)
             L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg,
-                          w_dg16=w_dg16))
+                          w_dg16=w_dg16, fold=fold))
             return y, d._y16
+
+        def _fold_forms(srcs, h, w, cout, wgt, head):
+            """Data-gradient form of the layer's weights with the flow member
+            folded into the x columns, for the two-member problem cat[x, skip]."""
+            cx, cs = srcs[0][1], srcs[1][1]
+            ctot = cx + cs + 2
+            w_eff = C.flow_fold_weights(_phys(wgt), cout, ctot, 0, cx, cx + cs,
+                                        head[0])
+            d2 = C.make_desc(list(srcs[:2]), B, h, w, cout, 3, 1, 1, True, act,
+                             module.mfma)
+            _, wd, _, wd16 = _prep(d2, w_eff, True, want16=twins)
+            return dict(desc=d2, w_dg=wd, w_dg16=wd16, keep=(w_eff,), cx=cx,
+                        cf_off=cx + cs, ctot=ctot, head=head)
 
         # encoder (activations travel as (f32 tensor, bf16 twin or None))
         e, h, w = [], H, W
@@ -218,7 +242,8 @@ class _PredictorFn(torch.autograd.Function):
                     (sk[0], ENC_CH[3 - i], C.NHWC, sk[1])]
             if f is not None:
                 srcs.append((f, 2, C.NCHW))
-            xx = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True)
+            xx = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True,
+                     head=(dec[i - 1][2], dec[i - 1][3]) if f is not None else None)
             x = xx[0]
             h, w, cx = 2 * h, 2 * w, DEC_CH[i]
             f = C.head_fwd(x, dec[i][2], dec[i][3], B, h, w, cx)
@@ -275,10 +300,25 @@ class _PredictorFn(torch.autograd.Function):
         sides = [side] + (ctx.module._extra_streams(dev) if side is not None else [])
         turn = [0]
 
-        def wgrad(desc, gz, gw, gb, unit, gz16=None):
+        # Flow member folded into weight space (csrc/flowfold.hip): a stage's
+        # weight gradient leaves its flow columns to dvsof_flow_fold_grads, which
+        # also ADDS the stage's share to the gradients of the head below -- so it
+        # runs once that head's own backward has written them: at the next
+        # weight gradient, ahead of it on the same stream.
+        pending = []
+
+        def wgrad(desc, gz, gw, gb, unit, gz16=None, fold=None):
+            def body():
+                for job in pending:
+                    job()
+                del pending[:]
+                C.conv_wgrad(desc, gz, gw, gb, gz16, skip_flat=fold is not None)
+                if fold is None:
+                    finish(unit)
+                else:
+                    pending.append(fold_job(desc, gz, gw, gb, unit, fold))
             if side is None:
-                C.conv_wgrad(desc, gz, gw, gb, gz16)
-                finish(unit)
+                body()
                 return
             s_ = sides[turn[0] % len(sides)]
             turn[0] += 1
@@ -286,9 +326,20 @@ class _PredictorFn(torch.autograd.Function):
             ready.record(main)
             s_.wait_event(ready)
             with torch.cuda.stream(s_):
-                C.conv_wgrad(desc, gz, gw, gb, gz16)
-                finish(unit)
+                body()
             keep.extend((gz, gz16))
+
+        def fold_job(desc, gz, gw, gb, unit, fold):
+            ho, wo = C.out_size(desc)
+            wh, bh = fold['head']
+            i_h = fold['head_idx']
+
+            def job():
+                C.flow_fold_grads(gw, _phys(fold['w']), desc.Cout, fold['ctot'], 0,
+                                  fold['cx'], fold['cf_off'], wh, bh, gb, gz, B, ho,
+                                  wo, grads[i_h], grads[i_h + 1])
+                finish(unit)
+            return job
 
         # ---- decoder, fine to coarse
         g_x = None          # gradient w.r.t. dec[i].y from the finer stage
@@ -304,7 +355,10 @@ class _PredictorFn(torch.autograd.Function):
             pw, pb, pfw, pfb = (po_dec + 4 * i + j for j in range(4))
             C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
                        grads[pfw], grads[pfb], B, h, w, d.Cout, gx16=gz16)
-            wgrad(d, gz, grads[pw], grads[pb], ('dec', i), gz16)
+            fold = lay.get('fold')
+            if fold is not None:
+                fold = dict(fold, w=params[pw], head_idx=po_dec + 4 * (i - 1) + 2)
+            wgrad(d, gz, grads[pw], grads[pb], ('dec', i), gz16, fold)
             srcs = lay['srcs']
             g_in = new(srcs[0][0])
             g_e = new(srcs[1][0])
@@ -314,11 +368,18 @@ class _PredictorFn(torch.autograd.Function):
                 # which the residual chain's data gradients read next
                 dsts[0]['actsrc'] = asrc(res_l[-1])
                 g_r16 = dsts[0]['p16'] = tw(g_in)
-            if len(srcs) == 3:
-                g_fprev = new(srcs[2][0])
-                dsts.append(dict(p=g_fprev, addend=gflows[i - 1]))
-            C.conv_dgrad(d, wt(lay), gz, dsts, act, weight16=lay['w_dg16'],
-                         gout16=gz16)
+            if fold is not None:
+                # cat[x, skip] with the folded weights: g_in already holds the
+                # path through the flow head, which then sees the loss gradient only
+                g_fprev = gflows[i - 1]
+                C.conv_dgrad(fold['desc'], fold['w_dg'], gz, dsts, act,
+                             weight16=fold['w_dg16'], gout16=gz16)
+            else:
+                if len(srcs) == 3:
+                    g_fprev = new(srcs[2][0])
+                    dsts.append(dict(p=g_fprev, addend=gflows[i - 1]))
+                C.conv_dgrad(d, wt(lay), gz, dsts, act, weight16=lay['w_dg16'],
+                             gout16=gz16)
             keep.append(gz16)
             g_skip[3 - i] = g_e
             if i > 0:

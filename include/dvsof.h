@@ -320,8 +320,12 @@ typedef struct {
     void *y16;           /* dvsof_conv2d_fwd: bf16 twin of y, written */
     const void *w16;     /* bf16 twin of the weight argument of the call
                             (dvsof_to_bf16 of the prepared form) */
-    const void *gout16;  /* dvsof_conv2d_dgrad: bf16 twin of gout */
+    const void *gout16;  /* dvsof_conv2d_dgrad / _wgrad: bf16 twin of gout */
+    int flags;           /* DVSOF_CONV_* bits */
 } dvsof_conv_desc_t;
+/* dvsof_conv2d_wgrad leaves the columns of the narrow planar members (the
+ * 2-channel flow) unwritten: dvsof_flow_fold_grads fills them (below) */
+#define DVSOF_CONV_WGRAD_SKIP_FLAT 1
 
 /*
  * Bytes of scratch dvsof_conv2d_fwd / dvsof_conv2d_dgrad need for this layer:
@@ -511,6 +515,35 @@ int dvsof_radam_step(const uint64_t *ptrs, const int64_t *sizes,
 
 /* Gradient centralisation (Ranger): grad[r][:] -= mean(grad[r][:]). */
 int dvsof_grad_centralize(float *grad, int rows, int row_len, void *stream);
+
+/* ------------------------------------------------------------------ *
+ * The flow member of a decoder stage in weight space (csrc/flowfold.hip).
+ * Stage i convolves cat[x, skip, flow] with flow = Wh x + bh, the previous
+ * stage's 1x1 flow head applied to the x member.  For the BACKWARD
+ * (utils/training.py:158 through the network) the member is folded away:
+ *   dvsof_flow_fold_weights   w_eff[Cout][9][Ctot-2] = the layer's weights
+ *       without the two flow columns, x columns += Wflow . Wh: the data
+ *       gradient then runs on cat[x, skip] alone and already contains the
+ *       path through the flow head (the head's backward gets the flow's LOSS
+ *       gradient only);
+ *   dvsof_flow_fold_grads     after dvsof_conv2d_wgrad with
+ *       DVSOF_CONV_WGRAD_SKIP_FLAT: writes the flow columns of dW from its x
+ *       columns, Wh, bh, the bias gradient db_conv and the border sums of the
+ *       output gradient g [B,H,W,Cout], and ADDS the stage's contribution to
+ *       the head's gradients dwh [2][Cx], dbh [2].
+ * cx_off / cf_off: first column of the x member / of the flow pair in a
+ * weight row; 3x3 taps; the flow is the member convolved at the x member's
+ * resolution (both up-sampled together).  ws: dvsof_flow_fold_workspace_bytes.
+ * ------------------------------------------------------------------ */
+int dvsof_flow_fold_weights(const float *w, int Cout, int Ctot, int cx_off,
+                            int Cx, int cf_off, const float *wh, float *w_eff,
+                            void *stream);
+size_t dvsof_flow_fold_workspace_bytes(int B, int Cout);
+int dvsof_flow_fold_grads(float *dW, const float *w, int Cout, int Ctot,
+                          int cx_off, int Cx, int cf_off, const float *wh,
+                          const float *bh, const float *db_conv,
+                          const float *g, int B, int H, int W, float *dwh,
+                          float *dbh, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------ *
  * Data-parallel gradient exchange (RCCL over xGMI).  The reference is single

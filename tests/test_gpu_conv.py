@@ -195,6 +195,66 @@ def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
     close(dw3, dwx, BF16_RTOL)
 
 
+@pytest.mark.parametrize('B,H,W,Cx,Cs,Cout', [
+    (2, 8, 8, 32, 32, 32),
+    (3, 6, 10, 64, 32, 64),          # odd frame sides, unequal members
+    (8, 32, 32, 64, 64, 32),         # a decoder-stage shape (K splits, sub-pixel fold)
+])
+def test_flow_member_folded_into_weight_space(B, H, W, Cx, Cs, Cout):
+    """Backward of a decoder stage whose input is cat[x, skip, flow] with
+    flow = Wh x + bh (the previous stage's head): the data gradient on
+    cat[x, skip] with the folded weights, the weight gradient with the flow
+    columns derived from the x columns + border sums, and the head's gradient
+    additions (csrc/flowfold.hip) against ATen autograd through
+    cat / interpolate / conv2d."""
+    from dvs_of_training_framework_amd import conv as C
+    g = torch.Generator().manual_seed(B * 7 + Cout)
+    x = torch.randn(B, Cx, H, W, generator=g, requires_grad=True)
+    sk = torch.randn(B, Cs, H, W, generator=g, requires_grad=True)
+    wh = (torch.randn(2, Cx, generator=g) / Cx ** 0.5).requires_grad_(True)
+    bh = torch.randn(2, generator=g, requires_grad=True)
+    ctot = Cx + Cs + 2
+    w = (torch.randn(Cout, ctot, 3, 3, generator=g) / (ctot * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    flow = F.conv2d(x, wh[:, :, None, None], bh)
+    inp = F.interpolate(torch.cat([x, sk, flow], 1), scale_factor=2, mode='nearest')
+    z = F.conv2d(inp, w, b, padding=1)
+    gz = torch.randn(z.shape, generator=g)
+    z.backward(gz)
+
+    x_d, sk_d = nhwc(x.detach()), nhwc(sk.detach())
+    flow_d = flow.detach().cuda().contiguous()
+    w_d, wh_d, bh_d = wphys(w.detach()), wh.detach().cuda().contiguous(), bh.detach().cuda()
+    gz_d = nhwc(gz)
+    # data gradient: two vector members, folded weights
+    d2 = C.make_desc([(x_d, Cx, C.NHWC), (sk_d, Cs, C.NHWC)], B, H, W, Cout, 3, 1, 1, True)
+    w_eff = C.flow_fold_weights(w_d, Cout, ctot, 0, Cx, Cx + Cs, wh_d)
+    _, w_dg = C.prepare(d2, w_eff, True)
+    gx = torch.empty(B, H, W, Cx, device='cuda')
+    gs = torch.empty(B, H, W, Cs, device='cuda')
+    C.conv_dgrad(d2, w_dg, gz_d, [dict(p=gx), dict(p=gs)])
+    close(from_nhwc(gx), x.grad)          # includes the path through the flow head
+    close(from_nhwc(gs), sk.grad)
+    # weight gradient: vector members on the matrix cores, flow columns in weight space
+    d3 = C.make_desc([(x_d, Cx, C.NHWC), (sk_d, Cs, C.NHWC), (flow_d, 2, C.NCHW)], B, H, W, Cout,
+                     3, 1, 1, True)
+    dw = torch.full((Cout, 3, 3, ctot), float('nan'), device='cuda')
+    db = torch.empty(Cout, device='cuda')
+    C.conv_wgrad(d3, gz_d, dw, db, skip_flat=True)
+    dwh = torch.zeros(2, Cx, device='cuda')
+    dbh = torch.zeros(2, device='cuda')
+    C.flow_fold_grads(dw, w_d, Cout, ctot, 0, Cx, Cx + Cs, wh_d, bh_d, db, gz_d, B, 2 * H, 2 * W,
+                      dwh, dbh)
+    close(dw.permute(0, 3, 1, 2), w.grad)
+    close(db, b.grad)
+    close(dwh, wh.grad)
+    close(dbh, bh.grad)
+    # the unfused path (flat-member kernels) gives the same weight gradient
+    dw2 = torch.empty(Cout, 3, 3, ctot, device='cuda')
+    C.conv_wgrad(d3, gz_d, dw2, db)
+    close(dw, dw2, 1e-5)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout,act', [
     (2, 8, 12, 32, 64, 'relu'),
     (1, 5, 7, 64, 48, 'mish'),        # odd sizes, Cout not a tile multiple
