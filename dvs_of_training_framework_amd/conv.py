@@ -26,7 +26,7 @@ class ConvDesc(ctypes.Structure):
                 ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i),
                 ('scratch', _vp), ('scratch_bytes', _sz),
                 ('winograd_input', _vp), ('y16', _vp), ('w16', _vp),
-                ('gout16', _vp), ('flags', _i)]
+                ('gout16', _vp), ('flags', _i), ('bias_cls', _vp)]
 
 
 class GradDst(ctypes.Structure):
@@ -62,6 +62,7 @@ _lib.register('dvsof_to_bf16_many', _i, [_P(_vp), _P(_vp), _P(ctypes.c_size_t), 
 _lib.register('dvsof_conv2d_scratch_bytes', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_flow_fold_weights', _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 _lib.register('dvsof_flow_fold_workspace_bytes', _sz, [_i, _i])
+_lib.register('dvsof_flow_fold_bias', _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 _lib.register('dvsof_flow_fold_grads', _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp,
                                             _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp])
 WGRAD_SKIP_FLAT = 1
@@ -171,7 +172,7 @@ def _scratch(desc, device):
 
 
 def conv_fwd(desc, weight, bias, device, residual=None, want_z=False,
-             keep_input_transform=False, weight16=None):
+             keep_input_transform=False, weight16=None, bias_cls=None):
     """-> y [B,Ho,Wo,Cout] (NHWC buffer), z or None.  In mode 3
     (MFMA_BF16_TWINS) ``desc._y16`` is y's bf16 twin afterwards.
     keep_input_transform: a Winograd layer's scratch (it starts with the
@@ -183,6 +184,7 @@ def conv_fwd(desc, weight, bias, device, residual=None, want_z=False,
     desc._y16 = twin(y) if desc.mfma == MFMA_BF16_TWINS else None
     desc.y16 = _lib.ptr(desc._y16)
     desc.w16 = _lib.ptr(weight16)
+    desc.bias_cls = _lib.ptr(bias_cls)
     ws = _scratch(desc, device)     # noqa: F841  (alive across the call)
     _lib.check(_lib.lib().dvsof_conv2d_fwd(
         ctypes.byref(desc), weight.data_ptr(), _lib.ptr(bias),
@@ -277,6 +279,16 @@ def flow_fold_weights(w, Cout, Ctot, cx_off, Cx, cf_off, wh):
         w.data_ptr(), Cout, Ctot, cx_off, Cx, cf_off, wh.data_ptr(),
         out.data_ptr(), _lib.stream()), 'dvsof_flow_fold_weights')
     return out
+
+
+def flow_fold_bias(w, Cout, Ctot, cf_off, bh, bias):
+    """-> (bias_eff [Cout], bias_cls [9][Cout]) (dvsof_flow_fold_bias)."""
+    be = torch.empty(Cout, dtype=torch.float32, device=w.device)
+    bc = torch.empty(9 * Cout, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().dvsof_flow_fold_bias(
+        w.data_ptr(), Cout, Ctot, cf_off, bh.data_ptr(), _lib.ptr(bias),
+        be.data_ptr(), bc.data_ptr(), _lib.stream()), 'dvsof_flow_fold_bias')
+    return be, bc
 
 
 def flow_fold_grads(dW, w, Cout, Ctot, cx_off, Cx, cf_off, wh, bh, db_conv, g,

@@ -620,6 +620,9 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     P.W = weight;
     P.W16 = d->mfma == 3 ? (const unsigned short *)d->w16 : nullptr;
     P.bias = bias;
+    P.bias_cls = d->bias_cls;
+    P.out_H = Ho;
+    P.out_W = Wo;
     P.zout = z;
     P.B = d->B;
     const int up = d->upsample ? 2 : 1;

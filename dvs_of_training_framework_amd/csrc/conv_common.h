@@ -48,6 +48,10 @@ struct GConvParams {
     const float *W;     // [N][taps][Cin_tot], K contiguous
     const unsigned short *W16;   // bf16 twin of W (mfma_bf16 == 3)
     const float *bias;  // [N] or null
+    const float *bias_cls;   // optional [9][N]: added to the rows of border class c = 1..8 of the
+                             // OUTPUT frame (3 * (top 1 | bottom 2) + (left 1 | right 2)); class 0
+                             // (interior) adds nothing.  A folded constant member's share (flowfold.hip)
+    int out_H, out_W;        // output frame of the class test (bias_cls only)
     float *zout;        // optional pre-activation copy, indexed like dst[0]
     int nsrc, ndst;
     int B, Hv, Wv;      // virtual input size (after up-sampling)
@@ -208,9 +212,15 @@ __device__ __forceinline__ void mfma_k16(f32x16 (&acc)[TM][TN], const f32x4 (&a)
 // store.  Measured: 21 us of a 30 us launch at 4.2 M outputs.)
 // acc[reg] <-> row (reg&3) + 8*(reg>>2) + 4*(lane>>5), column lane&31.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void conv_row_offsets(const GConvParams &P, long long *rowO, int BM, int r,
-                                                 bool valid, int b, int oy, int ox, int phy, int phx)
+__device__ __forceinline__ void conv_row_offsets(const GConvParams &P, long long *rowO, int *rowC, int BM,
+                                                 int r, bool valid, int b, int oy, int ox, int phy,
+                                                 int phx)
 {
+    if (P.bias_cls) {   // border class of the output pixel (phase problems: 2 * row + phase)
+        const int Y = P.nph == 4 ? 2 * oy + phy : oy, X = P.nph == 4 ? 2 * ox + phx : ox;
+        rowC[r] = valid ? 3 * (Y == 0 ? 1 : Y == P.out_H - 1 ? 2 : 0) + (X == 0 ? 1 : X == P.out_W - 1 ? 2 : 0)
+                        : 0;
+    }
     if (P.quad) {
         oy >>= 1;
         ox >>= 1;
@@ -225,8 +235,8 @@ __device__ __forceinline__ void conv_row_offsets(const GConvParams &P, long long
 
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc)[TM][TN],
-                                              const long long *rowO, int BM, int n0, int wr, int wc,
-                                              int lane)
+                                              const long long *rowO, const int *rowC, int BM, int n0,
+                                              int wr, int wc, int lane)
 {
     const int lrow = lane & 31;
     bool has_add = false, has_add2 = false, has_as = false;   // wave-uniform
@@ -272,6 +282,13 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
                     const long long r_ = ro[rbase + (reg & 3) + 8 * (reg >> 2)];
                     o[reg] = (col_ok && r_ >= 0) ? r_ + cpart : -1;
                     v[reg] = acc[tm][tn][reg] + bias;
+                }
+                if (P.bias_cls) {   // wave-uniform; border rows only load
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int c = rowC[rbase + (reg & 3) + 8 * (reg >> 2)];
+                        if (c != 0 && col_ok) v[reg] += P.bias_cls[c * P.N + n];
+                    }
                 }
                 if (has_add) {
                     float t[16];

@@ -56,6 +56,41 @@ __global__ __launch_bounds__(256) void flow_fold_weights_kernel(const float *__r
     weff[i] = v;
 }
 
+// bias_eff / bias_cls of the forward fold; thread per output channel
+__global__ __launch_bounds__(256) void flow_fold_bias_kernel(const float *__restrict__ w, int Cout,
+                                                             int Ctot, int cf_off,
+                                                             const float *__restrict__ bh,
+                                                             const float *__restrict__ bias,
+                                                             float *__restrict__ bias_eff,
+                                                             float *__restrict__ bias_cls)
+{
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= Cout) return;
+    float tap[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        const float *wf = w + ((size_t)co * TAPS + t) * Ctot + cf_off;
+        tap[t] = wf[0] * bh[0] + wf[1] * bh[1];
+    }
+    float all = 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) all += tap[t];
+    bias_eff[co] = (bias ? bias[co] : 0.f) + all;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int cy = c / 3, cx = c - 3 * cy;      // 1: first line (ky / kx = 0 outside), 2: last (2 outside)
+        float out = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int ky = t / 3, kx = t - 3 * ky;
+            const bool outside = (cy == 1 && ky == 0) || (cy == 2 && ky == 2) || (cx == 1 && kx == 0) ||
+                                 (cx == 2 && kx == 2);
+            if (outside) out += tap[t];
+        }
+        bias_cls[(size_t)c * Cout + co] = -out;
+    }
+}
+
 // Sums of g over the four border lines of every image: part[(line * B + b) * C + c],
 // line 0: y = 0, 1: y = H - 1, 2: x = 0, 3: x = W - 1.  One 1024-thread
 // workgroup per (line, image); thread = (pixel group r, channel c), 8 loads in
@@ -223,6 +258,17 @@ int dvsof_flow_fold_weights(const float *w, int Cout, int Ctot, int cx_off, int 
     const size_t n = (size_t)Cout * TAPS * (Ctot - 2);
     hipLaunchKernelGGL(flow_fold_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        as_stream(stream), w, Cout, Ctot, cx_off, Cx, cf_off, wh, w_eff);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_flow_fold_bias(const float *w, int Cout, int Ctot, int cf_off, const float *bh,
+                         const float *bias, float *bias_eff, float *bias_cls, void *stream)
+{
+    if (!w || !bh || !bias_eff || !bias_cls || Cout < 1 || Ctot < 3 || cf_off < 0 || cf_off + 2 > Ctot)
+        return DVSOF_EINVAL;
+    hipLaunchKernelGGL(flow_fold_bias_kernel, dim3((Cout + 255) / 256), dim3(256), 0, as_stream(stream), w,
+                       Cout, Ctot, cf_off, bh, bias, bias_eff, bias_cls);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
     __shared__ int rowB[BM], rowY[BM], rowX[BM];
     __shared__ long long rowO[3 * BM];   // output offsets (conv_epilogue)
+    __shared__ int rowC[BM];             // border class of the output row (bias_cls)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WCOLS, wc = wave % WCOLS;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
         rowB[r] = b;
         rowY[r] = y;
         rowX[r] = x;
-        conv_row_offsets(P, rowO, BM, r, m < P.M, b, oy, ox, phy, phx);
+        conv_row_offsets(P, rowO, rowC, BM, r, m < P.M, b, oy, ox, phy, phx);
     }
     __syncthreads();
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(CONV_NT) void gconv_kernel(const GConvParams P, con
     }
 
     // ---- epilogue (conv_common.h)
-    conv_epilogue<TM, TN>(P, acc, rowO, BM, n0, wr, wc, lane);
+    conv_epilogue<TM, TN>(P, acc, rowO, rowC, BM, n0, wr, wc, lane);
 }
 
 int count_steps(const GConvParams &P)

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     int *rowB = (int *)(smem + ROWINFO), *rowY = rowB + BM, *rowX = rowY + BM;
     long long *rowO = (long long *)(rowX + BM);   // [3][BM] output offsets (conv_epilogue)
+    int *rowC = (int *)(rowO + 3 * BM);           // [BM] border class of the output row (bias_cls)
 
     const int tid = threadIdx.x, lane = tid & 63;
     if (P.dbg & 512) return;      // probe: launch floor (dispatch + kernarg fetch)
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         rowB[r] = b;
         rowY[r] = y;
         rowX[r] = x;
-        conv_row_offsets(P, rowO, BM, r, m < P.M, b, oy, ox, phy, phx);
+        conv_row_offsets(P, rowO, rowC, BM, r, m < P.M, b, oy, ox, phy, phx);
     }
     __syncthreads();
     if (P.dbg & 1024) return;     // probe: + row tables
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
 
     if (P.dbg & 1) return;
     // ---- epilogue (conv_common.h)
-    conv_epilogue<TM, TN>(P, acc, rowO, BM, n0, wr, wc, lane);
+    conv_epilogue<TM, TN>(P, acc, rowO, rowC, BM, n0, wr, wc, lane);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -535,7 +536,7 @@ int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
 {
     constexpr int BM = WROWS * TM * 32, BN = WCOLS * TN * 32;
     constexpr int PA = BM / 16, PB0 = (BN + 15) / 16, PB = PB0 + ((4 - (PA + PB0) % 4) % 4);
-    constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * (sizeof(int) + sizeof(long long));
+    constexpr size_t LDS = (size_t)NS * KSUB * (PA + PB) * 1024 + 3 * BM * (sizeof(int) + sizeof(long long)) + BM * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         DVSOF_HIP_TRY(hipFuncSetAttribute(

@@ -17,6 +17,7 @@ backward pass is ~45 launches of the gather-conv / wgrad / head kernels with
 the gradient sums and activation derivatives folded into kernel epilogues
 (no autograd graph, no cat/upsample tensors, no elementwise passes).
 """
+import contextlib
 import math
 import os
 
@@ -120,7 +121,21 @@ class _PredictorFn(torch.autograd.Function):
         # second stream too, ahead of the data-gradient forms, and the main
         # stream waits for them once, at the first residual layer.
         pre, pre_ready = {}, None
-        if side is not None:
+
+        def _fold_pre(srcs2, hh, ww, cout_, wgt_, bias_, head):
+            cx, cs = srcs2[0][1], srcs2[1][1]
+            ctot = cx + cs + 2
+            w_eff = C.flow_fold_weights(_phys(wgt_), cout_, ctot, 0, cx, cx + cs, head[0])
+            b_eff, b_cls = C.flow_fold_bias(_phys(wgt_), cout_, ctot, cx + cs, head[1], bias_)
+            d2 = C.make_desc(list(srcs2), B, hh, ww, cout_, 3, 1, 1, True, act, module.mfma)
+            w_f, _, w_f16, _ = _prep(d2, w_eff, False, want16=twins)
+            return dict(w_eff=w_eff, w_fwd=w_f, w_fwd16=w_f16, bias=b_eff, bias_cls=b_cls,
+                        cx=cx, cf_off=cx + cs, ctot=ctot, head=head)
+
+        fold_pre = want_grad and os.environ.get('DVSOF_FLOW_FOLD', '1') != '0' and \
+            os.environ.get('DVSOF_FLOW_FOLD_FWD', '1') != '0' and \
+            len(module._extra_streams(dev)) == 0
+        if side is not None or fold_pre:
             h16, w16 = H // 16, W // 16
             specs = [(4 + 2 * i + j, [(x0, 512, C.NHWC)], h16, w16, 512,
                       res[i][2 * j], False)
@@ -133,16 +148,26 @@ class _PredictorFn(torch.autograd.Function):
                 specs.append((4 + 2 * NUM_RES + i, srcs_, hh, ww, DEC_CH[i],
                               dec[i][0], True))
                 cx_, hh, ww = DEC_CH[i], 2 * hh, 2 * ww
-            with torch.cuda.stream(side):
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 for li, srcs_, hh, ww, cout_, wgt_, up_ in specs:
+                    if fold_pre and len(srcs_) == 3:
+                        # decoder stage with a flow member: forward AND backward run
+                        # on cat[x, skip] with the head folded into the weights
+                        i_ = li - (4 + 2 * NUM_RES)
+                        pre[li] = _fold_pre(srcs_[:2], hh, ww, cout_, wgt_, dec[i_][1],
+                                            (dec[i_ - 1][2], dec[i_ - 1][3]))
+                        continue
+                    if side is None:
+                        continue        # the other forms are made where they are used
                     d_ = C.make_desc(srcs_, B, hh, ww, cout_, 3, 1, 1, up_, act,
                                      module.mfma)
                     w_f, _, w_f16, _ = _prep(d_, _phys(wgt_), False,
                                                  want16=twins)
                     if w_f is not wgt_:
                         pre[li] = (w_f, w_f16)
-            pre_ready = torch.cuda.Event()
-            pre_ready.record(side)
+            if side is not None:
+                pre_ready = torch.cuda.Event()
+                pre_ready.record(side)
         waited = [False]
         # bf16-twins mode: the twins of the weights that are used as they are
         # (stride-2 encoder layers, direct residual layers) in ONE launch; the
@@ -170,8 +195,27 @@ class _PredictorFn(torch.autograd.Function):
             first = len(L) == 0       # voxel input needs no data gradient
             need_dg = want_grad and not first
             w_fwd16 = w_dg16 = w_dg = fold = None
+            fpre = pre.get(len(L)) if isinstance(pre.get(len(L)), dict) else None
+            if fpre is not None:
+                # flow member folded (forward and backward): two vector members
+                if side is not None and not waited[0]:
+                    main.wait_event(pre_ready)
+                    waited[0] = True
+                d2 = C.make_desc(list(srcs[:2]), B, h, w, cout, 3, 1, 1, True, act,
+                                 module.mfma)
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    _, wd, _, wd16 = _prep(d2, fpre['w_eff'], True,
+                                           phase_weights=fpre['w_fwd'], want16=twins)
+                fold = dict(desc=d2, w_dg=wd, w_dg16=wd16, keep=(fpre,), cx=fpre['cx'],
+                            cf_off=fpre['cf_off'], ctot=fpre['ctot'], head=fpre['head'])
+                y, z = C.conv_fwd(d2, fpre['w_fwd'], fpre['bias'], dev, residual, mish,
+                                  keep_input_transform=want_grad,
+                                  weight16=fpre['w_fwd16'], bias_cls=fpre['bias_cls'])
+                L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=None,
+                              w_dg16=None, fold=fold))
+                return y, d2._y16
             if side is not None and need_dg:
-                if len(L) in pre:             # made on the second stream
+                if isinstance(pre.get(len(L)), tuple):    # made on the second stream
                     w_fwd, w_fwd16 = pre[len(L)]
                     if not waited[0]:
                         main.wait_event(pre_ready)

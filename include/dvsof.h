@@ -322,6 +322,11 @@ typedef struct {
                             (dvsof_to_bf16 of the prepared form) */
     const void *gout16;  /* dvsof_conv2d_dgrad / _wgrad: bf16 twin of gout */
     int flags;           /* DVSOF_CONV_* bits */
+    const float *bias_cls; /* dvsof_conv2d_fwd, optional: [9][Cout] added to the
+                            output rows of border class c = 3 * (top 1 |
+                            bottom 2) + (left 1 | right 2); row 0 (interior)
+                            is not read.  The position-dependent share of a
+                            folded constant member (dvsof_flow_fold_weights) */
 } dvsof_conv_desc_t;
 /* dvsof_conv2d_wgrad leaves the columns of the narrow planar members (the
  * 2-channel flow) unwritten: dvsof_flow_fold_grads fills them (below) */
@@ -538,6 +543,16 @@ int dvsof_grad_centralize(float *grad, int rows, int row_len, void *stream);
 int dvsof_flow_fold_weights(const float *w, int Cout, int Ctot, int cx_off,
                             int Cx, int cf_off, const float *wh, float *w_eff,
                             void *stream);
+/* The same fold for the FORWARD: y = conv(up cat[x, skip], w_eff) + bias_eff
+ * + bias_cls[class of the output pixel], where the head's bias bh reaches the
+ * output through the flow taps that lie inside the frame:
+ *   bias_eff[co]    = bias[co] + sum_{t,f} Wflow[co][t][f] bh[f]
+ *   bias_cls[c][co] = - sum_{t outside for class c, f} Wflow[co][t][f] bh[f]
+ * (3x3 taps, pad 1; rows of the first / last output line lose ky = 0 / 2,
+ * columns kx = 0 / 2).  bias_cls is [9][Cout], row 0 zero. */
+int dvsof_flow_fold_bias(const float *w, int Cout, int Ctot, int cf_off,
+                         const float *bh, const float *bias, float *bias_eff,
+                         float *bias_cls, void *stream);
 size_t dvsof_flow_fold_workspace_bytes(int B, int Cout);
 int dvsof_flow_fold_grads(float *dW, const float *w, int Cout, int Ctot,
                           int cx_off, int Cx, int cf_off, const float *wh,

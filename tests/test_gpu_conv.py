@@ -229,7 +229,17 @@ def test_flow_member_folded_into_weight_space(B, H, W, Cx, Cs, Cout):
     # data gradient: two vector members, folded weights
     d2 = C.make_desc([(x_d, Cx, C.NHWC), (sk_d, Cs, C.NHWC)], B, H, W, Cout, 3, 1, 1, True)
     w_eff = C.flow_fold_weights(w_d, Cout, ctot, 0, Cx, Cx + Cs, wh_d)
-    _, w_dg = C.prepare(d2, w_eff, True)
+    w_f, w_dg = C.prepare(d2, w_eff, True)
+    # forward on cat[x, skip]: the head's bias arrives through the in-frame flow
+    # taps only -> a bias per border class of the output pixel
+    b_eff, b_cls = C.flow_fold_bias(w_d, Cout, ctot, Cx + Cs, bh_d, b.detach().cuda())
+    y_f, z_f = C.conv_fwd(d2, w_f, b_eff, 'cuda', None, want_z=True, bias_cls=b_cls)
+    close(from_nhwc(z_f), z)
+    d3f = C.make_desc([(x_d, Cx, C.NHWC), (sk_d, Cs, C.NHWC), (flow_d, 2, C.NCHW)], B, H, W, Cout,
+                      3, 1, 1, True)
+    w_f3, _ = C.prepare(d3f, w_d, False)
+    _, z_3 = C.conv_fwd(d3f, w_f3, b.detach().cuda(), 'cuda', None, want_z=True)
+    close(from_nhwc(z_f), from_nhwc(z_3), 1e-5)
     gx = torch.empty(B, H, W, Cx, device='cuda')
     gs = torch.empty(B, H, W, Cs, device='cuda')
     C.conv_dgrad(d2, w_dg, gz_d, [dict(p=gx), dict(p=gs)])
