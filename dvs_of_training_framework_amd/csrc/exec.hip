@@ -51,7 +51,6 @@ struct Exec {
     std::vector<hipEvent_t> join;    // per side lane
     int n_kernels = 0, n_events = 0, n_waits = 0;
     int max_lanes = 1;
-    bool calibrated = false;
 };
 
 // From lanes to waits and events: a node waits for its dependencies in other
@@ -271,7 +270,6 @@ int dvsof_exec_info(void *exec, int *n_kernels, int *n_lanes, int *n_events, int
     if (!exec) return DVSOF_EINVAL;
     Exec *x = (Exec *)exec;
     if (n_kernels) *n_kernels = x->n_kernels;
-    (void)x->calibrated;
     if (n_lanes) *n_lanes = (int)x->tail.size();
     if (n_events) *n_events = x->n_events;
     if (n_waits) *n_waits = x->n_waits;
@@ -341,7 +339,6 @@ int dvsof_exec_calibrate(void *exec, void *stream)
         if (e) (void)hipEventDestroy(e);
     if (rc) return rc;
     plan_by_time(x);
-    x->calibrated = true;
     return wire(x);
 }
 
