@@ -121,8 +121,10 @@ def make_desc(srcs, B, H, W, Cout, ksize=3, stride=1, pad=1, upsample=False,
         d.src[i].layout = layout
         d.src[i].p16 = _lib.ptr(src[3]) if len(src) > 3 else None
     d.B, d.H, d.W = B, H, W
-    d.upsample = UP_ZERO if upsample == UP_ZERO and upsample is not True \
-        else (1 if upsample else 0)
+    if upsample is True or upsample is False:
+        upsample = UP_NEAREST if upsample else UP_NONE
+    assert upsample in (UP_NONE, UP_NEAREST, UP_ZERO)
+    d.upsample = upsample
     d.ksize, d.stride, d.pad = ksize, stride, pad
     d.Cout, d.act, d.mfma = Cout, act, mfma
     return d

@@ -132,8 +132,10 @@ class _PredictorFn(torch.autograd.Function):
             return dict(w_eff=w_eff, w_fwd=w_f, w_fwd16=w_f16, bias=b_eff, bias_cls=b_cls,
                         cx=cx, cf_off=cx + cs, ctot=ctot, head=head)
 
+        # Decoder stages whose third member is the previous stage's flow run, when
+        # training, on cat[x, skip] with that member folded into weight space
+        # (csrc/flowfold.hip; DVSOF_FLOW_FOLD=0: the member as a member)
         fold_pre = want_grad and os.environ.get('DVSOF_FLOW_FOLD', '1') != '0' and \
-            os.environ.get('DVSOF_FLOW_FOLD_FWD', '1') != '0' and \
             len(module._extra_streams(dev)) == 0
         if side is not None or fold_pre:
             h16, w16 = H // 16, W // 16
@@ -178,15 +180,10 @@ class _PredictorFn(torch.autograd.Function):
             raw16 = {id(w_): t_ for w_, t_ in
                      zip(raws, C.to_bf16_many([_phys(w_) for w_ in raws]))}
 
-        fold_on = want_grad and os.environ.get('DVSOF_FLOW_FOLD', '1') != '0' and \
-            len(module._extra_streams(dev)) == 0
-
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
-                residual=None, head=None):
+                residual=None):
             """-> (y, y16): the layer's output and, in the bf16-twins mode,
-            its bf16 copy (written by the same kernel).  head = (Wh, bh) of
-            the flow head whose output is the layer's third member: the
-            backward folds that member into weight space (csrc/flowfold.hip)."""
+            its bf16 copy (written by the same kernel)."""
             d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act,
                             module.mfma)
             # prepared weights: sub-pixel phase kernels for the decoder,
@@ -227,18 +224,12 @@ class _PredictorFn(torch.autograd.Function):
                         ev.record(main)
                         side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    if head is not None and fold_on:
-                        fold = _fold_forms(srcs, h, w, cout, wgt, head)
-                    else:
-                        _, w_dg, _, w_dg16 = _prep(d, _phys(wgt), True,
-                                                   phase_weights=w_fwd,
-                                                   want16=twins)
+                    _, w_dg, _, w_dg16 = _prep(d, _phys(wgt), True,
+                                               phase_weights=w_fwd,
+                                               want16=twins)
             else:
-                folded = head is not None and fold_on and need_dg
                 w_fwd, w_dg, w_fwd16, w_dg16 = _prep(
-                    d, _phys(wgt), need_dg and not folded, want16=twins)
-                if folded:
-                    fold = _fold_forms(srcs, h, w, cout, wgt, head)
+                    d, _phys(wgt), need_dg, want16=twins)
             if twins and w_fwd16 is None:
                 w_fwd16 = raw16.get(id(wgt))
                 if w_fwd16 is None or w_fwd is not wgt:
@@ -249,19 +240,6 @@ class _PredictorFn(torch.autograd.Function):
             L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg,
                           w_dg16=w_dg16, fold=fold))
             return y, d._y16
-
-        def _fold_forms(srcs, h, w, cout, wgt, head):
-            """Data-gradient form of the layer's weights with the flow member
-            folded into the x columns, for the two-member problem cat[x, skip]."""
-            cx, cs = srcs[0][1], srcs[1][1]
-            ctot = cx + cs + 2
-            w_eff = C.flow_fold_weights(_phys(wgt), cout, ctot, 0, cx, cx + cs,
-                                        head[0])
-            d2 = C.make_desc(list(srcs[:2]), B, h, w, cout, 3, 1, 1, True, act,
-                             module.mfma)
-            _, wd, _, wd16 = _prep(d2, w_eff, True, want16=twins)
-            return dict(desc=d2, w_dg=wd, w_dg16=wd16, keep=(w_eff,), cx=cx,
-                        cf_off=cx + cs, ctot=ctot, head=head)
 
         # encoder (activations travel as (f32 tensor, bf16 twin or None))
         e, h, w = [], H, W
@@ -286,8 +264,7 @@ class _PredictorFn(torch.autograd.Function):
                     (sk[0], ENC_CH[3 - i], C.NHWC, sk[1])]
             if f is not None:
                 srcs.append((f, 2, C.NCHW))
-            xx = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True,
-                     head=(dec[i - 1][2], dec[i - 1][3]) if f is not None else None)
+            xx = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True)
             x = xx[0]
             h, w, cx = 2 * h, 2 * w, DEC_CH[i]
             f = C.head_fwd(x, dec[i][2], dec[i][3], B, h, w, cx)
