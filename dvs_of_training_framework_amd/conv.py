@@ -331,6 +331,26 @@ def head_fwd(x, w, bias, B, H, W, C):
     return flow
 
 
+_lib.register('dvsof_flow_heads_fwd', _i, [_i, _P(_vp), _P(_vp), _P(_vp), _P(_vp), _i,
+                                           _P(_i), _P(_i), _P(_i), _vp])
+
+
+def heads_fwd(items, B, out=None):
+    """items: [(x NHWC, w, bias, H, W, C)] (at most 4) -> [flow NCHW] from ONE
+    launch (dvsof_flow_heads_fwd); ``out``: preallocated flow tensors."""
+    n = len(items)
+    flows = out if out is not None else [
+        torch.empty(B, 2, H, W, dtype=torch.float32, device=x.device)
+        for x, _, _, H, W, _ in items]
+    arr = lambda ts: (_vp * n)(*[_lib.ptr(t) for t in ts])        # noqa: E731
+    ints = lambda k: (_i * n)(*[it[k] for it in items])             # noqa: E731
+    _lib.check(_lib.lib().dvsof_flow_heads_fwd(
+        n, arr([it[0] for it in items]), arr([it[1] for it in items]),
+        arr([it[2] for it in items]), arr(flows), B, ints(3), ints(4), ints(5),
+        _lib.stream()), 'dvsof_flow_heads_fwd')
+    return flows
+
+
 def head_bwd(x, w, gflow, gx_in, actsrc, act, gx, dw, dbias, B, H, W, C,
              gx16=None):
     nbytes = _lib.lib().dvsof_flow_head_bwd_workspace_bytes(B, H, W, C)

@@ -309,18 +309,17 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float *__rest
 // LPP = C/4 lanes share one pixel (one float4 of channels each).
 
 template <int LPP>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ x,
-                                                       const float *__restrict__ w,
-                                                       const float *__restrict__ bias,
-                                                       float *__restrict__ flow, int B, int HW)
+__device__ __forceinline__ void head_fwd_body(const float *__restrict__ x, const float *__restrict__ w,
+                                              const float *__restrict__ bias, float *__restrict__ flow,
+                                              int B, int HW, int vblock, int nblocks)
 {
     constexpr int C = LPP * 4, PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, sub = lane % LPP, pw = lane / LPP;
     const f32x4 w0 = *(const f32x4u *)(w + 4 * sub), w1 = *(const f32x4u *)(w + C + 4 * sub);
     const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
     const long long total = (long long)B * HW;
-    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long nwaves = (long long)gridDim.x * 4;
+    const long long wave_id = (long long)vblock * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)nblocks * 4;
     for (long long base = wave_id * PPW; base < total; base += nwaves * PPW) {
         const long long pix = base + pw;
         float p0 = 0.f, p1 = 0.f;
@@ -339,6 +338,41 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
             flow[(b * 2) * HW + r] = p0 + b0;
             flow[(b * 2 + 1) * HW + r] = p1 + b1;
         }
+    }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ x,
+                                                       const float *__restrict__ w,
+                                                       const float *__restrict__ bias,
+                                                       float *__restrict__ flow, int B, int HW)
+{
+    head_fwd_body<LPP>(x, w, bias, flow, B, HW, blockIdx.x, gridDim.x);
+}
+
+// Up to 4 heads in ONE launch (the training forward with the flow member folded:
+// nothing between the decoder stages reads a flow, so all of them are computed
+// ahead of the loss; a launch of this size is mostly its ~4.5 us of dispatch)
+constexpr int HEADS_MAX = 4;
+struct HeadsFwd {
+    const float *x[HEADS_MAX], *w[HEADS_MAX], *bias[HEADS_MAX];
+    float *flow[HEADS_MAX];
+    int HW[HEADS_MAX], C[HEADS_MAX], block_begin[HEADS_MAX + 1];
+    int B, n;
+};
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const HeadsFwd A)
+{
+    int h = 0;
+#pragma unroll
+    for (int i = 1; i < HEADS_MAX; ++i)
+        if (i < A.n && (int)blockIdx.x >= A.block_begin[i]) h = i;
+    const int vb = blockIdx.x - A.block_begin[h], nb = A.block_begin[h + 1] - A.block_begin[h];
+    switch (A.C[h] / 4) {
+    case 4: head_fwd_body<4>(A.x[h], A.w[h], A.bias[h], A.flow[h], A.B, A.HW[h], vb, nb); break;
+    case 8: head_fwd_body<8>(A.x[h], A.w[h], A.bias[h], A.flow[h], A.B, A.HW[h], vb, nb); break;
+    case 16: head_fwd_body<16>(A.x[h], A.w[h], A.bias[h], A.flow[h], A.B, A.HW[h], vb, nb); break;
+    case 32: head_fwd_body<32>(A.x[h], A.w[h], A.bias[h], A.flow[h], A.B, A.HW[h], vb, nb); break;
+    default: head_fwd_body<64>(A.x[h], A.w[h], A.bias[h], A.flow[h], A.B, A.HW[h], vb, nb); break;
     }
 }
 
@@ -1092,6 +1126,36 @@ int dvsof_flow_head_fwd(const float *x, const float *w, const float *bias, float
     long long nbl = ((long long)B * H * W + per_block - 1) / per_block;
     const int nb = (int)(nbl < 1 ? 1 : nbl > 65535 ? 65535 : nbl);
     HEAD_DISPATCH(head_fwd_kernel, nb, x, w, bias, flow, B, H * W);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_flow_heads_fwd(int n, const float *const *x, const float *const *w, const float *const *bias,
+                         float *const *flow, int B, const int *H, const int *W, const int *C,
+                         void *stream)
+{
+    if (n < 1 || n > HEADS_MAX || !x || !w || !flow || !H || !W || !C || B < 1) return DVSOF_EINVAL;
+    static const int fwd_iters = getenv("DVSOF_HEAD_FWD_ITERS") ? atoi(getenv("DVSOF_HEAD_FWD_ITERS")) : 4;
+    HeadsFwd A = {};
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!x[i] || !w[i] || !flow[i] || H[i] < 1 || W[i] < 1 || !head_c_ok(C[i])) return DVSOF_EINVAL;
+        A.x[i] = x[i];
+        A.w[i] = w[i];
+        A.bias[i] = bias ? bias[i] : nullptr;
+        A.flow[i] = flow[i];
+        A.HW[i] = H[i] * W[i];
+        A.C[i] = C[i];
+        const long long per_block = 4LL * (64 / (C[i] / 4)) * (fwd_iters > 0 ? fwd_iters : 1);
+        long long nbl = ((long long)B * H[i] * W[i] + per_block - 1) / per_block;
+        nbl = nbl < 1 ? 1 : nbl > 65535 ? 65535 : nbl;
+        A.block_begin[i] = (int)blocks;
+        blocks += nbl;
+    }
+    A.block_begin[n] = (int)blocks;
+    A.B = B;
+    A.n = n;
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), A);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

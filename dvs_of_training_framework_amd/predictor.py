@@ -257,7 +257,7 @@ class _PredictorFn(torch.autograd.Function):
             r = run([(t[0], 512, C.NHWC, t[1])], h, w, 512, res[i][2],
                     res[i][3], residual=r[0])
         # decoder
-        flows, xx, cx, f = [], r, 512, None
+        flows, xx, cx, f, heads = [], r, 512, None, []
         for i in range(4):
             sk = e[3 - i]
             srcs = [(xx[0], cx, C.NHWC, xx[1]),
@@ -267,8 +267,16 @@ class _PredictorFn(torch.autograd.Function):
             xx = run(srcs, h, w, DEC_CH[i], dec[i][0], dec[i][1], up=True)
             x = xx[0]
             h, w, cx = 2 * h, 2 * w, DEC_CH[i]
-            f = C.head_fwd(x, dec[i][2], dec[i][3], B, h, w, cx)
+            if fold_pre:
+                # folded: no later stage reads this flow -- all four heads run in
+                # one launch after the last stage (the tensor is only named here)
+                f = torch.empty(B, 2, h, w, dtype=torch.float32, device=dev)
+                heads.append((x, dec[i][2], dec[i][3], h, w, cx))
+            else:
+                f = C.head_fwd(x, dec[i][2], dec[i][3], B, h, w, cx)
             flows.append(f)
+        if heads:
+            C.heads_fwd(heads, B, out=flows)
         if want_grad:
             ctx.dg_ready = None
             if side is not None:

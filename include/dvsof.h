@@ -425,6 +425,14 @@ int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize,
  */
 int dvsof_flow_head_fwd(const float *x, const float *w, const float *bias,
                         float *flow, int B, int H, int W, int C, void *stream);
+/* n <= 4 heads in one launch (host arrays of device pointers / sizes; bias may
+ * be NULL or hold NULLs): the training forward computes all flows ahead of the
+ * loss once nothing between the decoder stages reads them. */
+int dvsof_flow_heads_fwd(int n, const float *const *host_x,
+                         const float *const *host_w,
+                         const float *const *host_bias, float *const *host_flow,
+                         int B, const int *host_H, const int *host_W,
+                         const int *host_C, void *stream);
 
 size_t dvsof_flow_head_bwd_workspace_bytes(int B, int H, int W, int C);
 /*
