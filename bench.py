@@ -90,8 +90,8 @@ def parse():
                         'launches from one C call on the eager schedule\'s two streams); the default '
                         'on one GPU')
     p.add_argument('--eager', action='store_true',
-                   help='enqueue every step from Python (the default under data parallelism, where '
-                        'the gradient exchange is not captured)')
+                   help='enqueue every step from Python (torch.distributed issues the gradient '
+                        'exchange under data parallelism)')
     p.add_argument('--no-other-modes', action='store_true',
                    help='skip the short bf16x3 / bf16 runs reported beside the fp32 headline')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -129,8 +129,8 @@ class Harness:
         self.captured_all = {}
 
     def step(self):
-        if (getattr(self.a, 'graph', False) or getattr(self.a, 'executor', False)) \
-                and self.reducer is None:
+        if getattr(self.a, 'executor', False) or \
+                (getattr(self.a, 'graph', False) and self.reducer is None):
             return self.graph_step()
         return self.eager_step()
 
@@ -141,22 +141,23 @@ class Harness:
         k = self.i % len(self.batches)
         self.i += 1
         if k not in self.captured_all:
-            from dvs_of_training_framework_amd.capture import CapturedTrainStep
+            from dvs_of_training_framework_amd.capture import CaptureFailed, CapturedTrainStep
             try:
+                # under data parallelism the exchange is part of the captured step:
+                # the executor issues the bucket all-reduces between its launches
                 self.captured = self.captured_all[k] = CapturedTrainStep(
                     self.model, self.losses, self.opt, [0.5, 1, 1], self.device, self.batches[k],
-                    executor=bool(getattr(self.a, 'executor', False)), bind=True)
-            except Exception as e:      # noqa: BLE001 -- the launch mode, not the product path:
-                # the same kernels are enqueued from Python instead, and the JSON line says so
+                    executor=bool(getattr(self.a, 'executor', False)), bind=True,
+                    reducer=self.reducer)
+            except CaptureFailed as e:  # the launch mode, not the product path: this batch's
+                # step is done (eagerly); later ones are enqueued from Python, the JSON line says so
                 import traceback
                 traceback.print_exc()
-                self.launch_fallback = f'capture failed ({type(e).__name__}: {e}); eager launches'
+                self.launch_fallback = f'capture failed ({e}); eager launches'
                 self.suspend_graph()
-                if hasattr(self.opt, 'end_capture'):
-                    self.opt.end_capture()
                 self.opt.zero_grad(set_to_none=True)
-                self.i -= 1
-                return self.eager_step()
+                self.sched.step()
+                return e.loss
             loss = self.captured.first_loss
         else:
             loss, _ = self.captured_all[k]()
@@ -471,8 +472,12 @@ def cpu_baseline(a):
 
 def main():
     a = parse()
+    if os.environ.get('DVSOF_EAGER') == '1':        # (sweep scripts set modes through the environment)
+        a.eager = True
+    if os.environ.get('DVSOF_DTYPE'):
+        a.dtype = os.environ['DVSOF_DTYPE']
     if not (a.eager or a.graph):
-        a.executor = True       # (Harness.step falls back to eager launches under a reducer)
+        a.executor = True
     launch_mode = (a.graph, a.executor)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     from dvs_of_training_framework_amd import parallel
@@ -541,7 +546,9 @@ def main():
         ex = h.captured.executor
         out['config']['launch'] = 'one hipGraph replay per step' if ex is None else (
             f'step executor: {ex.kernels} kernels on {ex.lanes} streams {ex.lane_kernels}, '
-            f'{ex.events} events / {ex.waits} waits per step, one C call')
+            f'{ex.events} events / {ex.waits} waits per step, one C call'
+            + (f'; {ex.marks} exchange marks (bucket all-reduces issued by the executor on the '
+               'exchange stream)' if ex.marks else ''))
     if not a.no_roofline:
         h.suspend_graph()       # per-launch HIP events need eager launches
         roof = measure_roofline(h, dt / a.steps * 1e3)   # every rank runs the same steps

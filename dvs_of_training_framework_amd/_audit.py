@@ -1,0 +1,163 @@
+"""Pointer audit of a captured step (debug tool; capture.CapturedTrainStep.audit).
+
+A captured graph replays kernels with the ARGUMENT VALUES of the recording.
+A device pointer among them that belongs to an eager torch tensor which nobody
+holds any more is a fault waiting for the allocator to reuse the block (round
+2: ``Model._layout_cache`` dropped index vectors a graph still read).  The
+rule the capture relies on: every pointer a kernel argument carries lies
+
+  * in the graph's private memory pool (tensors made while recording), or
+  * in a tensor the step keeps alive: ``step._keep``, the static input
+    buffers, model parameters / buffers, optimizer state, the step's outputs,
+    module-level constants (the unit seed of loss.unit_backward).
+
+This walk checks it node by node.  Argument layouts come from the AMDGPU code
+object metadata of libdvsof_hip.so (``llvm-readelf --notes`` on the gfx950
+code objects of the fat binary: per kernel the explicit arguments with offset,
+size and kind); argument bytes come from the captured nodes
+(``dvsof_exec_node_arg``).  ``global_buffer`` arguments are pointers;
+by-value structs (descriptors with embedded pointers) are scanned as aligned
+8-byte words, a word counting as a pointer when it falls inside a segment of
+torch's caching allocator.  Kernels of other libraries (two ATen gathers in
+the step) have no metadata here and are listed as ``foreign``.
+"""
+import ctypes
+import re
+import struct
+import subprocess
+from pathlib import Path
+
+import torch
+
+from . import _lib
+
+_READELF = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+_MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
+_LAYOUTS = None
+
+
+def _code_objects(path):
+    data = Path(path).read_bytes()
+    for m in re.finditer(re.escape(_MAGIC), data):
+        p = m.start()
+        n = struct.unpack_from('<Q', data, p + 24)[0]
+        off = p + 32
+        for _ in range(n):
+            o, sz, ts = struct.unpack_from('<QQQ', data, off)
+            triple = data[off + 24:off + 24 + ts].decode(errors='replace')
+            off += 24 + ts
+            if sz and 'amdgcn' in triple:
+                yield data[p + o:p + o + sz]
+
+
+def kernel_layouts():
+    """{mangled kernel name: [(size, is_pointer)] of the explicit arguments}."""
+    global _LAYOUTS
+    if _LAYOUTS is not None:
+        return _LAYOUTS
+    import tempfile
+    import yaml
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, blob in enumerate(_code_objects(_lib.LIB_PATH)):
+            f = Path(tmp) / f'{i}.co'
+            f.write_bytes(blob)
+            text = subprocess.run([_READELF, '--notes', str(f)], capture_output=True,
+                                  text=True, check=True).stdout
+            a = text.find('---')
+            b = text.find('...', a)
+            if a < 0:
+                continue
+            meta = yaml.safe_load(text[a + 3:b if b > 0 else None])
+            for k in (meta or {}).get('amdhsa.kernels', []):
+                args = [(int(x['.size']), x['.value_kind'] == 'global_buffer')
+                        for x in k.get('.args', [])
+                        if not str(x['.value_kind']).startswith('hidden_')]
+                out[k['.name']] = args
+    _LAYOUTS = out
+    return out
+
+
+def _tensors(obj, seen, out):
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _tensors(v, seen, out)
+    elif isinstance(obj, (list, tuple, set)):
+        for v in obj:
+            _tensors(v, seen, out)
+
+
+def held_ranges(step):
+    """[(lo, hi)] address ranges of the storages the step keeps alive."""
+    from . import loss as loss_mod
+    roots = [step._keep, step.static, step.loss, getattr(step._terms, 'packed', None),
+             list(step.model.parameters()), list(step.model.buffers()),
+             [v for st in step.optimizer.state.values() for v in st.values()],
+             [p.grad for p in step.model.parameters()],
+             list(loss_mod._UNIT.values()), getattr(step.optimizer, '_dyn', None)]
+    ts = []
+    _tensors(roots, set(), ts)
+    ranges = []
+    for t in ts:
+        s = t.untyped_storage()
+        ranges.append((s.data_ptr(), s.data_ptr() + s.nbytes()))
+    return ranges
+
+
+def audit_step(step):
+    assert step.executor is not None, 'the audit reads the nodes through the step executor'
+    layouts = kernel_layouts()
+    pool = tuple(step.graph.pool())
+    segs = []
+    for seg in torch.cuda.memory_snapshot():
+        segs.append((seg['address'], seg['address'] + seg['total_size'],
+                     tuple(seg.get('segment_pool_id', (0, 0))) == pool))
+    held = held_ranges(step)
+
+    def where(v):
+        for lo, hi, in_pool in segs:
+            if lo <= v < hi:
+                if in_pool:
+                    return 'pool'
+                return 'held' if any(a <= v < b for a, b in held) else 'unheld'
+        return None         # not a device address of this allocator
+
+    x = step.executor
+    res = {'nodes': 0, 'audited': 0, 'foreign': [], 'pointers': 0, 'pool': 0, 'held': 0,
+           'unheld': []}
+    i = 0
+    lane, us, nw = (ctypes.c_int(), ctypes.c_float(), ctypes.c_int())
+    buf = ctypes.create_string_buffer(2048)
+    while _lib.lib().dvsof_exec_node(x._handle, i, ctypes.byref(lane), ctypes.byref(us),
+                                     ctypes.byref(nw), buf, 2048) == 0:
+        name = buf.value.decode(errors='replace')
+        i += 1
+        if name in ('(empty)', '?'):
+            continue
+        res['nodes'] += 1
+        args = layouts.get(name)
+        if args is None:
+            res['foreign'].append(name[:80])
+            continue
+        res['audited'] += 1
+        for k, (size, is_ptr) in enumerate(args):
+            if size < 8:
+                continue
+            raw = x.node_arg(i - 1, k, size)
+            words = struct.unpack_from(f'<{size // 8}Q', raw)
+            for w in (words[:1] if is_ptr else words):
+                kind = where(w)
+                if kind is None:
+                    continue
+                res['pointers'] += 1
+                if kind == 'unheld':
+                    res['unheld'].append((i - 1, name[:60], k, hex(w)))
+                else:
+                    res[kind] += 1
+    return res

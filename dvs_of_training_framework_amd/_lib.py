@@ -5,13 +5,17 @@ raises.  PyTorch is used only for device memory and streams; every entry
 point gets raw device pointers and the current HIP stream.
 """
 import ctypes
+import os
 import re
 from pathlib import Path
 
 import torch
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / 'libdvsof_hip.so'
+# DVSOF_PROBE_LIB=1: the probe build (`make -C csrc probes`; timing probes of
+# DVSOF_GCONV_DBG / DVSOF_LOSS_DBG compiled in) -- diagnostics tools only
+LIB_PATH = _PKG / ('libdvsof_hip_probes.so' if os.environ.get('DVSOF_PROBE_LIB') == '1'
+                   else 'libdvsof_hip.so')
 HEADER_PATH = _PKG.parent / 'include' / 'dvsof.h'
 MAX_SCALES = 8
 
@@ -45,6 +49,10 @@ _SIGNATURES = {
     'dvsof_exec_node': (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_f),
                              ctypes.POINTER(_i), ctypes.c_char_p, _i]),
     'dvsof_exec_destroy': (_i, [_vp]),
+    'dvsof_exec_mark': (_i, [_i, _i, _vp, _sz, _vp]),
+    'dvsof_exec_set_comm': (_i, [_vp, _vp, _vp]),
+    'dvsof_exec_marks': (_i, [_vp, ctypes.POINTER(_i)]),
+    'dvsof_exec_node_arg': (_i, [_vp, _i, _i, _sz, _vp]),
     'dvsof_count_image': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     'dvsof_voxelize_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                 _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -111,7 +111,7 @@ int dvsof_augment_lut(const double *cos_sin, int B, int H, int W, int32_t *lut, 
         return DVSOF_EINVAL;
     hipStream_t st = as_stream(stream);
     const long long n = (long long)B * H * W;
-    DVSOF_HIP_TRY(hipMemsetAsync(lut, 0x7f, sizeof(int32_t) * (size_t)n, st));   // 0x7f7f7f7f: empty
+    DVSOF_HIP_TRY((hipError_t)fill_u32(lut, 0x7f7f7f7fu, sizeof(int32_t) * (size_t)n, st));   // 0x7f7f7f7f: empty
     hipLaunchKernelGGL(aug_lut_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, cos_sin, B, H,
                        W, lut);
     DVSOF_LAUNCH_CHECK();

@@ -26,6 +26,12 @@ struct Rccl {
     bool ok = false;
 };
 
+// what dvsof_comm_create hands out
+struct Comm {
+    ncclComm_t c = nullptr;
+    int world = 1;
+};
+
 Rccl &rccl()
 {
     static Rccl r;
@@ -67,9 +73,13 @@ int dvsof_comm_create(void **comm, int world_size, int rank, const void *host_id
     if (!r.ok) return DVSOF_ECOMM;
     ncclUniqueId id;
     memcpy(&id, host_id128, sizeof(id));
-    ncclComm_t c = nullptr;
-    if (r.comm_init_rank(&c, world_size, id, rank) != ncclSuccess) return DVSOF_ECOMM;
-    *comm = (void *)c;
+    Comm *cm = new Comm;
+    cm->world = world_size;
+    if (r.comm_init_rank(&cm->c, world_size, id, rank) != ncclSuccess) {
+        delete cm;
+        return DVSOF_ECOMM;
+    }
+    *comm = (void *)cm;
     return DVSOF_OK;
 }
 
@@ -78,7 +88,10 @@ int dvsof_comm_destroy(void *comm)
     if (!comm) return DVSOF_EINVAL;
     Rccl &r = rccl();
     if (!r.ok) return DVSOF_ECOMM;
-    return r.comm_destroy((ncclComm_t)comm) == ncclSuccess ? DVSOF_OK : DVSOF_ECOMM;
+    Comm *cm = (Comm *)comm;
+    const bool ok = r.comm_destroy(cm->c) == ncclSuccess;
+    delete cm;
+    return ok ? DVSOF_OK : DVSOF_ECOMM;
 }
 
 int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream)
@@ -88,9 +101,14 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream)
     Rccl &r = rccl();
     if (!r.ok) return DVSOF_ECOMM;
     // in place, average over the ranks: the mean of per-rank gradients is the
-    // global-batch gradient (equal per-rank batch)
-    return r.all_reduce(bucket, bucket, n, ncclFloat32, ncclAvg, (ncclComm_t)comm, as_stream(stream)) ==
-                   ncclSuccess
+    // global-batch gradient (equal per-rank batch).  RCCL
+    // implements ncclAvg as a pre-multiplied sum; in a group of ONE that is a
+    // scaled-copy kernel per bucket (oneRankReduce<FuncPreMulSum>, 10-50 us
+    // each) for a factor of 1.0 -- the sum over one rank is the same average
+    // and RCCL returns from it without launching anything.
+    Comm *cm = (Comm *)comm;
+    return r.all_reduce(bucket, bucket, n, ncclFloat32, cm->world == 1 ? ncclSum : ncclAvg, cm->c,
+                        as_stream(stream)) == ncclSuccess
                ? DVSOF_OK
                : DVSOF_ECOMM;
 }

@@ -15,7 +15,47 @@
 
 static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 
+// Timing probes (DVSOF_GCONV_DBG / DVSOF_LOSS_DBG: skip pieces of a kernel to
+// see what they cost; results are wrong by construction) exist only in the
+// PROBE build (`make probes` -> libdvsof_hip_probes.so, -DDVSOF_PROBES).  In
+// the product library DVSOF_DBG(P) is the constant 0: no runtime wrong-result
+// switch, no dead scalar tests in the hot loops.
+#ifdef DVSOF_PROBES
+#define DVSOF_DBG(P) ((P).dbg)
+#else
+#define DVSOF_DBG(P) 0
+#endif
+
 constexpr int kWave = 64;  // gfx950 wavefront
+
+// Stream-ordered fill by a KERNEL.  hipMemsetAsync becomes a memset NODE in a
+// captured hipGraph: the step executor (exec.hip) replays kernel nodes only,
+// and re-launching a graph with a memset node while its previous replay was
+// still in flight is the suspected cause of round 1's "write to a read-only
+// page" fault.  Every zero-fill the library enqueues is therefore a kernel.
+static __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ p, uint32_t v, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;    // words up to 16-byte alignment
+    if (head > n) head = n;
+    if (i < head) p[i] = v;
+    uint4 *q = (uint4 *)(p + head);
+    const size_t nq = (n - head) / 4;
+    for (size_t k = i; k < nq; k += stride) q[k] = make_uint4(v, v, v, v);
+    const size_t done = head + nq * 4;
+    if (i < n - done) p[done + i] = v;
+}
+// nbytes: a multiple of 4 (float / int32 buffers)
+static inline int fill_u32(void *p, uint32_t v, size_t nbytes, hipStream_t st)
+{
+    const size_t n = nbytes / 4;
+    if (n == 0) return DVSOF_OK;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)p, v, n);
+    return (int)hipGetLastError();
+}
 
 // Sum over the 64 lanes of a wave; the result is valid in EVERY lane.
 // 32-bit types: DPP row shifts + row broadcasts + one v_readlane, all VALU --

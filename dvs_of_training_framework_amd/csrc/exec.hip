@@ -26,16 +26,39 @@
 //
 // The graph must consist of kernel nodes (and empty nodes); it has to stay
 // alive while the executor is (kernel arguments are read from the nodes).
+//
+// Data parallelism.  The gradient exchange is not a kernel of ours: while a
+// step is captured parallel.GradReducer leaves MARKS in the capture instead
+// of collectives (dvsof_exec_mark: a one-thread no-op kernel whose arguments
+// name the bucket).  The executor recognises the marks by their function
+// address and never launches them: a BUCKET mark becomes "record an event on
+// the lane that closed the bucket, make the exchange stream wait for it,
+// ncclAllReduce (average, in place) on the exchange stream"; the JOIN mark in
+// front of the optimizer becomes "the lane waits for the exchange stream".
+// Same collectives in the same order on every rank (the launch order is a
+// property of the captured graph, identical across replicas).  Without a
+// communicator (dvsof_exec_set_comm not called: one GPU) marks are skipped.
 #include "common.h"
 #include <algorithm>
+#include <string.h>
 #include <unordered_map>
 #include <vector>
 
 namespace {
 
+// kind: DVSOF_MARK_BUCKET / DVSOF_MARK_JOIN.  Never runs under the executor;
+// under hipGraphLaunch it is a no-op (and the exchange is then missing: the
+// captured step refuses that combination).
+__global__ void exec_mark_kernel(int kind, int index, float *bucket, size_t n) {}
+
 struct XNode {
     hipKernelNodeParams kp;
     bool kernel;
+    int mark = 0;            // DVSOF_MARK_*: not launched
+    int mark_index = 0;
+    float *mark_ptr = nullptr;
+    size_t mark_n = 0;
+    hipEvent_t mark_ev = nullptr;   // BUCKET: the lane's progress the exchange stream waits for
     int lane;
     float us = 1.f;          // measured duration (dvsof_exec_calibrate)
     std::vector<int> deps;   // positions of the nodes this one depends on
@@ -49,8 +72,11 @@ struct Exec {
     std::vector<int> tail;           // last node of every lane
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;    // per side lane
-    int n_kernels = 0, n_events = 0, n_waits = 0;
+    int n_kernels = 0, n_events = 0, n_waits = 0, n_marks = 0;
     int max_lanes = 1;
+    void *comm = nullptr;            // dvsof_comm_create handle (not owned)
+    hipStream_t xstream = nullptr;   // exchange stream (not owned)
+    hipEvent_t xdone = nullptr;      // exchange stream's progress at a JOIN mark
 };
 
 // From lanes to waits and events: a node waits for its dependencies in other
@@ -137,17 +163,93 @@ void plan_by_time(Exec *x)
 
 void destroy(Exec *x)
 {
-    for (auto &n : x->nodes)
+    for (auto &n : x->nodes) {
         if (n.ev) (void)hipEventDestroy(n.ev);
+        if (n.mark_ev) (void)hipEventDestroy(n.mark_ev);
+    }
+    if (x->xdone) (void)hipEventDestroy(x->xdone);
     if (x->fork) (void)hipEventDestroy(x->fork);
     for (auto e : x->join)
         if (e) (void)hipEventDestroy(e);
     delete x;
 }
 
+int launch_node(const XNode &n, hipStream_t st)
+{
+    if (n.kp.kernelParams) {
+        DVSOF_HIP_TRY(hipLaunchKernel(n.kp.func, n.kp.gridDim, n.kp.blockDim, n.kp.kernelParams,
+                                      n.kp.sharedMemBytes, st));
+    } else {
+        DVSOF_HIP_TRY(hipModuleLaunchKernel((hipFunction_t)n.kp.func, n.kp.gridDim.x, n.kp.gridDim.y,
+                                            n.kp.gridDim.z, n.kp.blockDim.x, n.kp.blockDim.y,
+                                            n.kp.blockDim.z, n.kp.sharedMemBytes, st, nullptr,
+                                            n.kp.extra));
+    }
+    return DVSOF_OK;
+}
+
+// A mark at its place in the launch order, on the stream `st` of its lane.
+int run_mark(Exec *x, XNode &n, hipStream_t st)
+{
+    if (!x->comm) return DVSOF_OK;   // one GPU: nothing to exchange
+    hipStream_t xs = x->xstream ? x->xstream : st;
+    if (n.mark == DVSOF_MARK_BUCKET) {
+        if (xs != st) {
+            DVSOF_HIP_TRY(hipEventRecord(n.mark_ev, st));
+            DVSOF_HIP_TRY(hipStreamWaitEvent(xs, n.mark_ev, 0));
+        }
+        return dvsof_allreduce_bucket(x->comm, n.mark_ptr, n.mark_n, (void *)xs);
+    }
+    if (n.mark == DVSOF_MARK_JOIN && xs != st) {
+        DVSOF_HIP_TRY(hipEventRecord(x->xdone, xs));
+        DVSOF_HIP_TRY(hipStreamWaitEvent(st, x->xdone, 0));
+    }
+    return DVSOF_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int dvsof_exec_mark(int kind, int index, float *bucket, size_t n, void *stream)
+{
+    if (kind != DVSOF_MARK_BUCKET && kind != DVSOF_MARK_JOIN) return DVSOF_EINVAL;
+    if (kind == DVSOF_MARK_BUCKET && (!bucket || n == 0)) return DVSOF_EINVAL;
+    hipLaunchKernelGGL(exec_mark_kernel, dim3(1), dim3(1), 0, as_stream(stream), kind, index, bucket, n);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+int dvsof_exec_set_comm(void *exec, void *comm, void *exchange_stream)
+{
+    if (!exec) return DVSOF_EINVAL;
+    Exec *x = (Exec *)exec;
+    x->comm = comm;
+    x->xstream = as_stream(exchange_stream);
+    if (comm && !x->xdone) DVSOF_HIP_TRY(hipEventCreateWithFlags(&x->xdone, hipEventDisableTiming));
+    for (auto &n : x->nodes)
+        if (comm && n.mark == DVSOF_MARK_BUCKET && !n.mark_ev)
+            DVSOF_HIP_TRY(hipEventCreateWithFlags(&n.mark_ev, hipEventDisableTiming));
+    return DVSOF_OK;
+}
+
+int dvsof_exec_marks(void *exec, int *n_marks)
+{
+    if (!exec || !n_marks) return DVSOF_EINVAL;
+    *n_marks = ((Exec *)exec)->n_marks;
+    return DVSOF_OK;
+}
+
+int dvsof_exec_node_arg(void *exec, int i, int arg, size_t nbytes, void *out)
+{
+    if (!exec || !out) return DVSOF_EINVAL;
+    Exec *x = (Exec *)exec;
+    if (i < 0 || i >= (int)x->nodes.size() || arg < 0) return DVSOF_EINVAL;
+    const XNode &n = x->nodes[i];
+    if (!n.kernel || !n.kp.kernelParams || !n.kp.kernelParams[arg]) return DVSOF_EINVAL;
+    memcpy(out, n.kp.kernelParams[arg], nbytes);
+    return DVSOF_OK;
+}
 
 int dvsof_exec_create(void *graph_, void *const *side_streams, int n_side, void **out)
 {
@@ -225,7 +327,15 @@ int dvsof_exec_create(void *graph_, void *const *side_streams, int n_side, void 
                 destroy(x);
                 return DVSOF_EINVAL;
             }
-            ++x->n_kernels;
+            if (n.kp.func == (void *)exec_mark_kernel && n.kp.kernelParams) {
+                n.mark = *(const int *)n.kp.kernelParams[0];
+                n.mark_index = *(const int *)n.kp.kernelParams[1];
+                n.mark_ptr = *(float *const *)n.kp.kernelParams[2];
+                n.mark_n = *(const size_t *)n.kp.kernelParams[3];
+                ++x->n_marks;
+            } else {
+                ++x->n_kernels;
+            }
         } else if (ty != hipGraphNodeTypeEmpty) {
             destroy(x);
             return DVSOF_EINVAL;      // memset / memcpy / host nodes: not a kernels-only step
@@ -276,7 +386,7 @@ int dvsof_exec_info(void *exec, int *n_kernels, int *n_lanes, int *n_events, int
     if (lane_kernels) {
         for (int l = 0; l < max_lanes; ++l) lane_kernels[l] = 0;
         for (auto &n : x->nodes)
-            if (n.kernel && n.lane < max_lanes) ++lane_kernels[n.lane];
+            if (n.kernel && !n.mark && n.lane < max_lanes) ++lane_kernels[n.lane];
     }
     return DVSOF_OK;
 }
@@ -313,16 +423,15 @@ int dvsof_exec_calibrate(void *exec, void *stream)
         DVSOF_HIP_TRY(hipEventRecord(ev[0], st));
         for (int i = 0; i < nn; ++i) {
             XNode &n = x->nodes[i];
-            if (n.kernel) {
-                if (n.kp.kernelParams) {
-                    DVSOF_HIP_TRY(hipLaunchKernel(n.kp.func, n.kp.gridDim, n.kp.blockDim, n.kp.kernelParams,
-                                                  n.kp.sharedMemBytes, st));
-                } else {
-                    DVSOF_HIP_TRY(hipModuleLaunchKernel((hipFunction_t)n.kp.func, n.kp.gridDim.x,
-                                                        n.kp.gridDim.y, n.kp.gridDim.z, n.kp.blockDim.x,
-                                                        n.kp.blockDim.y, n.kp.blockDim.z,
-                                                        n.kp.sharedMemBytes, st, nullptr, n.kp.extra));
+            if (n.mark) {
+                // the exchange in stream order on the one stream of this pass
+                if (x->comm && n.mark == DVSOF_MARK_BUCKET) {
+                    const int rc_ = dvsof_allreduce_bucket(x->comm, n.mark_ptr, n.mark_n, (void *)st);
+                    if (rc_) return rc_;
                 }
+            } else if (n.kernel) {
+                const int rc_ = launch_node(n, st);
+                if (rc_) return rc_;
             }
             DVSOF_HIP_TRY(hipEventRecord(ev[i + 1], st));
         }
@@ -330,7 +439,7 @@ int dvsof_exec_calibrate(void *exec, void *stream)
         for (int i = 0; i < nn; ++i) {
             float ms = 0.f;
             DVSOF_HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            x->nodes[i].us = x->nodes[i].kernel ? std::max(ms * 1e3f, 0.5f) : 0.f;
+            x->nodes[i].us = x->nodes[i].mark ? 0.f : x->nodes[i].kernel ? std::max(ms * 1e3f, 0.5f) : 0.f;
         }
         return DVSOF_OK;
     };
@@ -356,16 +465,12 @@ int dvsof_exec_launch(void *exec, void *stream)
     for (auto &n : x->nodes) {
         hipStream_t st = lane_stream(n.lane);
         for (int d : n.wait) DVSOF_HIP_TRY(hipStreamWaitEvent(st, x->nodes[d].ev, 0));
-        if (n.kernel) {
-            if (n.kp.kernelParams) {
-                DVSOF_HIP_TRY(hipLaunchKernel(n.kp.func, n.kp.gridDim, n.kp.blockDim, n.kp.kernelParams,
-                                              n.kp.sharedMemBytes, st));
-            } else {
-                DVSOF_HIP_TRY(hipModuleLaunchKernel((hipFunction_t)n.kp.func, n.kp.gridDim.x,
-                                                    n.kp.gridDim.y, n.kp.gridDim.z, n.kp.blockDim.x,
-                                                    n.kp.blockDim.y, n.kp.blockDim.z,
-                                                    n.kp.sharedMemBytes, st, nullptr, n.kp.extra));
-            }
+        if (n.mark) {
+            const int rc_ = run_mark(x, n, st);
+            if (rc_) return rc_;
+        } else if (n.kernel) {
+            const int rc_ = launch_node(n, st);
+            if (rc_) return rc_;
         }
         if (n.ev) DVSOF_HIP_TRY(hipEventRecord(n.ev, st));
     }

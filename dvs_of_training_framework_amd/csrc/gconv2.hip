@@ -72,7 +72,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     int *rowC = (int *)(rowO + 3 * BM);           // [BM] border class of the output row (bias_cls)
 
     const int tid = threadIdx.x, lane = tid & 63;
-    if (P.dbg & 512) return;      // probe: launch floor (dispatch + kernarg fetch)
+    if (DVSOF_DBG(P) & 512) return;      // probe: launch floor (dispatch + kernarg fetch)
     // wave-uniform values must live in SGPRs: otherwise hipcc wraps every
     // LDS-DMA in a waterfall loop over "possibly divergent" descriptors
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
         conv_row_offsets(P, rowO, rowC, BM, r, m < P.M, b, oy, ox, phy, phx);
     }
     __syncthreads();
-    if (P.dbg & 1024) return;     // probe: + row tables
+    if (DVSOF_DBG(P) & 1024) return;     // probe: + row tables
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                 const int sub = sub0 + wgrp * KPW;
                 // dbg 128: every K step re-reads the first chunk (true 64-B-segment access
                 // pattern, cache-resident footprint)
-                const int a_soff = (PROBE && (P.dbg & 128)) ? 0 : __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
-                const int b_soff = (PROBE && (P.dbg & 128)) ? 0 : __builtin_amdgcn_readfirstlane(
+                const int a_soff = (PROBE && (DVSOF_DBG(P) & 128)) ? 0 : __builtin_amdgcn_readfirstlane((it_c0 + sub * BK) * 4);
+                const int b_soff = (PROBE && (DVSOF_DBG(P) & 128)) ? 0 : __builtin_amdgcn_readfirstlane(
                     ((it_ky * P.ks + it_kx) * P.Cin_tot + it_coff) * EB + (it_c0 + sub * BK) * 4);
                 unsigned char *st = smem + stage_idx * STAGE + sub * SUB;
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                     // PA is a multiple of 4 and wave < 4: slot i holds an A piece iff
                     // i < PA / 4 (compile-time: no scalar compare + branch per load)
                     static_assert(PA % 4 == 0, "A pieces per wave");
-                    if (PROBE && (P.dbg & 4)) {   // timing probe: every load hits the same few KiB (L2-resident)
+                    if (PROBE && (DVSOF_DBG(P) & 4)) {   // timing probe: every load hits the same few KiB (L2-resident)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, slot_kq4[i] + (lane >> 2) * 64, 0, 0, 0);
                     } else if (i < PA / 4)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, dst, 16, voff[i], a_soff, 0, 0);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (P.dbg & 2048) return;     // probe: + ring prologue (first operands landed)
+        if (DVSOF_DBG(P) & 2048) return;     // probe: + ring prologue (first operands landed)
         load_frags(std::integral_constant<int, 0>{}, smem + wgrp * KPW * SUB);
 
         // The K loop in two parts: a steady part (every range test of a stage is
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                 auto step = [&](auto curc) {
                     constexpr int cur = decltype(curc)::value;
                     if (sub + 1 < KPW) {
-                        if (STEADY || !(P.dbg & 16))
+                        if (STEADY || !(DVSOF_DBG(P) & 16))
                             load_frags(std::integral_constant<int, cur ^ 1>{},
                                        stage + (sub + 1 + wgrp * KPW) * SUB);
                     } else if (STEADY || s + 1 < nvec) {
@@ -471,10 +471,10 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         }
                         // every wave holds its stage-s fragments in registers: slot u is free
-                        if (STEADY || !(P.dbg & 32)) __builtin_amdgcn_s_barrier();
+                        if (STEADY || !(DVSOF_DBG(P) & 32)) __builtin_amdgcn_s_barrier();
                         if constexpr (STEADY) issue_impl(std::false_type{}, u);
-                        else if (s + NS < nvec && !(P.dbg & 8)) issue_impl(std::true_type{}, u);
-                        if (STEADY || !(P.dbg & 16))
+                        else if (s + NS < nvec && !(DVSOF_DBG(P) & 8)) issue_impl(std::true_type{}, u);
+                        if (STEADY || !(DVSOF_DBG(P) & 16))
                             load_frags(std::integral_constant<int, cur ^ 1>{},
                                        smem + ((u + 1) % NS) * STAGE + wgrp * KPW * SUB);
                     }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
             static_assert(NS <= 4, "ring turns are written out for up to 4 stages");
         };
         // steady turns: s0 + NS - 1 + NS < nvec for the last stage of the turn
-        const int nsteady = (P.dbg != 0 || nvec < 2 * NS) ? 0 : (nvec - 2 * NS + 1) / NS * NS;
+        const int nsteady = (DVSOF_DBG(P) != 0 || nvec < 2 * NS) ? 0 : (nvec - 2 * NS + 1) / NS * NS;
         int s0 = 0;
         for (; s0 < nsteady; s0 += NS) ring_turn(std::true_type{}, s0);
         for (; s0 < nvec; s0 += NS) ring_turn(std::false_type{}, s0);
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
                 for (int r = 0; r < 16; ++r) acc[a][b][r] += xch[((a * TN + b) * 16 + r) * 64 + lane];
     }
 
-    if (P.dbg & 1) return;
+    if (DVSOF_DBG(P) & 1) return;
     // ---- epilogue (conv_common.h)
     conv_epilogue<TM, TN>(P, acc, rowO, rowC, BM, n0, wr, wc, lane);
 #endif  // __HIP_DEVICE_COMPILE__
@@ -580,7 +580,11 @@ bool gconv2_eligible(const GConvParams &P, long long max_src_bytes, long long w_
 int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
 {
     GConvParams P = P0;
+#ifdef DVSOF_PROBES
     static const int dbg = getenv("DVSOF_GCONV_DBG") ? atoi(getenv("DVSOF_GCONV_DBG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     P.dbg = dbg;
     const int taps = P.ks * P.ks;
     // bf16 twins: every vector member needs its twin, the weights theirs, and a

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int bid = blockIdx.x;
-    if (P.dbg & 128) return;
+    if (DVSOF_DBG(P) & 128) return;
     const int k = find_scale(P, bid);
     const ScaleDev &S = P.s[k];
     const int local = bid - S.block_begin;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
             sev[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (vy1 & vx1) ? o10 + 4 : OOB, 0, 0));
             prv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                 r0, valid[j] ? (unsigned)((y * w + x) * 4) : OOB, 0, 0));
-            if (P.dbg & 4) nwv[j] = nev[j] = swv[j] = sev[j] = prv[j] = u;     // probe: keeps the loads dead
+            if (DVSOF_DBG(P) & 4) nwv[j] = nev[j] = swv[j] = sev[j] = prv[j] = u;     // probe: keeps the loads dead
         }
     }
 
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     // photometric + out-of-border, utils/loss.py:58-74, 96-119
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        if (!valid[j] || (P.dbg & 2)) continue;
+        if (!valid[j] || (DVSOF_DBG(P) & 2)) continue;
         const float ax = axv[j], ay = ayv[j], cx = 1.f - ax, cy = 1.f - ay;
         const float nw = nwv[j], ne = nev[j], sw = swv[j], se = sev[j];
         const float warped = nw * cx * cy + ne * ax * cy + sw * cx * ay + se * ax * ay;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     // Branch-free: the LDS halo is zero-filled outside the frame, so every pair
     // can be evaluated and then multiplied by its 0/1 validity.  The two flow
     // channels of a pair go through the arithmetic together (packed f32).
-    if (!(P.dbg & 1)) {
+    if (!(DVSOF_DBG(P) & 1)) {
         const float mx = x < w ? 1.f : 0.f, mxr = x + 1 < w ? 1.f : 0.f;
         float mrow[6];                     // rows -1..4 of the strip inside the frame
 #pragma unroll
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
     // grids, bumps the arrival counter, stores its own gradients while that
     // atomic is in flight, and combines everything if it was the last.
     auto store_grads = [&]() {
-        if (!BWD || (P.dbg & 8)) return;
+        if (!BWD || (DVSOF_DBG(P) & 8)) return;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             if (!valid[j]) continue;
@@ -448,16 +448,16 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
             G[hw] = gv[j];
         }
     };
-    if (!FWD || (P.dbg & 16)) {
+    if (!FWD || (DVSOF_DBG(P) & 16)) {
         store_grads();
         return;
     }
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const float v = (P.dbg & 32) ? acc[i] : wave_sum(acc[i]);
+        const float v = (DVSOF_DBG(P) & 32) ? acc[i] : wave_sum(acc[i]);
         if (lane == 0) red[wave][i] = v;
     }
-    if (P.dbg & 64) {
+    if (DVSOF_DBG(P) & 64) {
         store_grads();
         return;
     }
@@ -566,10 +566,10 @@ __global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, con
     __shared__ float buf[2][PYR_MAXR];
     __shared__ int red[NT / kWave];
     if ((int)blockIdx.x >= Q.nblocks) {
-        if (do_count && !(P.dbg & 256)) count_oob_block(P, blockIdx.x - Q.nblocks, red);
+        if (do_count && !(DVSOF_DBG(P) & 256)) count_oob_block(P, blockIdx.x - Q.nblocks, red);
         return;
     }
-    if (P.dbg & 512) return;
+    if (DVSOF_DBG(P) & 512) return;
     const int tid = threadIdx.x, K = Q.K;
     const int d = blockIdx.x / Q.tiles_per_frame;
     const int t = blockIdx.x - d * Q.tiles_per_frame;
@@ -704,7 +704,11 @@ void bind_ws(Params &P, void *ws, int nb, float *terms, float *loss_out, const f
     P.loss_out = loss_out;
     for (int i = 0; i < 3; ++i) P.wts[i] = w ? w[i] : 0.f;
     P.loss_scale = loss_scale;
+#ifdef DVSOF_PROBES
     static const int dbg = getenv("DVSOF_LOSS_DBG") ? atoi(getenv("DVSOF_LOSS_DBG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     P.dbg = dbg;
 }
 

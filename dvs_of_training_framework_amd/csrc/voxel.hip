@@ -7,7 +7,7 @@
 //
 // HBM-bound integer/byte work.  v1: one thread per event, coalesced reads of
 // the five event columns, scatter with memory-side atomics into the grid that
-// was zero-filled on the same stream.
+// was zero-filled on the same stream (by a kernel: fill_u32, common.h).
 #include "common.h"
 #include <stdlib.h>
 
@@ -71,7 +71,7 @@ int dvsof_count_image(const int64_t *x, const int64_t *y, int64_t n, int H, int 
                       void *stream)
 {
     if (!out || H < 1 || W < 1 || n < 0 || (n > 0 && (!x || !y))) return DVSOF_EINVAL;
-    DVSOF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(uint32_t) * (size_t)H * W, as_stream(stream)));
+    DVSOF_HIP_TRY((hipError_t)fill_u32(out, 0u, sizeof(uint32_t) * (size_t)H * W, as_stream(stream)));
     if (n == 0) return DVSOF_OK;
     hipLaunchKernelGGL(count_image_kernel, dim3(grid_for(n)), dim3(NT), 0, as_stream(stream), x, y,
                        n, H, W, out);
@@ -85,7 +85,7 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t, const
 {
     if (!out || B < 1 || C < 1 || H < 1 || W < 1 || n < 0 || !t0 || !t1) return DVSOF_EINVAL;
     if (n > 0 && (!x || !y || !t || !pol || !sample)) return DVSOF_EINVAL;
-    DVSOF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * H * W, as_stream(stream)));
+    DVSOF_HIP_TRY((hipError_t)fill_u32(out, 0u, sizeof(float) * (size_t)B * C * H * W, as_stream(stream)));
     if (n == 0) return DVSOF_OK;
     hipLaunchKernelGGL(voxelize_kernel, dim3(grid_for(n)), dim3(NT), 0, as_stream(stream), x, y, t,
                        pol, sample, n, t0, t1, B, C, H, W, out, bin0, lin0);
@@ -426,7 +426,7 @@ void v2_bind(VoxV2 &P, void *workspace)
 int v2_launch(const VoxV2 &P, int flags, hipStream_t st)
 {
     if (!(flags & DVSOF_VOX_WS_CLEAN))
-        DVSOF_HIP_TRY(hipMemsetAsync(P.cursor, 0, v2_control_bytes(P), st));
+        DVSOF_HIP_TRY((hipError_t)fill_u32(P.cursor, 0u, v2_control_bytes(P), st));
     const int64_t n = P.n;
     static const int ept_env = getenv("DVSOF_VOX_EPT") ? atoi(getenv("DVSOF_VOX_EPT")) : 0;
     if (ept_env == 16 || (ept_env == 0 && n >= EPT16_FROM))
@@ -522,7 +522,7 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
     if (!out || B < 1 || C < 1 || H < 1 || W < 1 || n < 0 || !t0 || !t1) return DVSOF_EINVAL;
     hipStream_t st = as_stream(stream);
     if (n == 0) {
-        DVSOF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * H * W, st));
+        DVSOF_HIP_TRY((hipError_t)fill_u32(out, 0u, sizeof(float) * (size_t)B * C * H * W, st));
         return DVSOF_OK;
     }
     if (!x || !y || !t || !polarity || !sample_event_offsets || !workspace) return DVSOF_EINVAL;

@@ -34,6 +34,35 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
+_EXCHANGE_STREAMS = {}      # device index -> the stream of the collectives
+
+
+def claim_streams(device):
+    """Create AND USE the three streams of a training step -- the current
+    stream, the backward's weight-gradient stream, the exchange stream --
+    before any RCCL communicator exists.  ROCclr binds a stream to one of
+    GPU_MAX_HW_QUEUES hardware queues when it is first used (least-loaded
+    queue first); a communicator brings internal streams of its own, and a
+    stream first used after two communicators existed was seen sharing ONE
+    hardware queue with the weight-gradient stream (rocprofv3 kernel trace,
+    profiles/round3): a hardware queue is in order, so the exchange stream's
+    wait for "bucket ready" then holds back every weight-gradient kernel
+    queued behind it -- 4.8-4.95 instead of 3.25 ms per step at batch 8.
+    -> (weight-gradient stream or None, exchange stream)."""
+    from .predictor import Predictor
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    side = Predictor._wgrad_stream(None, dev)
+    if key not in _EXCHANGE_STREAMS:
+        _EXCHANGE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        for s in (torch.cuda.current_stream(dev), side, _EXCHANGE_STREAMS[key]):
+            if s is not None:
+                with torch.cuda.stream(s):
+                    torch.zeros(64, device=dev).add_(1.0)     # a kernel: the queue is bound now
+        torch.cuda.synchronize(dev)
+    return side, _EXCHANGE_STREAMS[key]
+
+
 def init_distributed(device_type='cuda'):
     """Initialise from the torchrun environment (RANK, LOCAL_RANK, WORLD_SIZE,
     MASTER_ADDR, MASTER_PORT).  -> (rank, local_rank, world_size)."""
@@ -47,6 +76,8 @@ def init_distributed(device_type='cuda'):
         backend = 'nccl' if device_type == 'cuda' else 'gloo'
         if device_type == 'cuda':
             torch.cuda.set_device(local)
+            if os.environ.get('DVSOF_NO_STREAM_CLAIM') != '1':
+                claim_streams(torch.device('cuda', local))     # before the communicators' streams
             with _stdout_to_stderr():
                 dist.init_process_group(backend, rank=rank, world_size=world,
                                         device_id=torch.device('cuda', local))
@@ -74,8 +105,31 @@ class GradReducer:
         self._side = None
         self.bytes_reduced = 0
         self._comm = None
+        self._direct = direct
+        self._events = {}            # bucket address -> its "ready" event, reused every step
+        self._marked = 0             # marks left in the capture in progress
         if direct:
             self._comm = self._make_comm()
+
+    def comm_handle(self):
+        """The C ABI's RCCL communicator (dvsof_comm_create), made on first
+        use -- a COLLECTIVE call: every rank gets here at the same point (the
+        first captured step that exchanges gradients)."""
+        if self._comm is None:
+            self._comm = self._make_comm()
+        return self._comm
+
+    def exchange_stream(self, device):
+        """Stream of the collectives.  DVSOF_EXCHANGE_ON_WGRAD_STREAM=1: the
+        backward's second stream (no third stream, the collectives queue up
+        between the weight-gradient kernels) -- a measurement switch."""
+        if os.environ.get('DVSOF_EXCHANGE_ON_WGRAD_STREAM') == '1':
+            from .predictor import _SIDE_STREAMS
+            key = torch.device(device).index
+            key = torch.cuda.current_device() if key is None else key
+            if key in _SIDE_STREAMS:
+                return _SIDE_STREAMS[key]
+        return self._side_stream(device)
 
     def _make_comm(self):
         import ctypes
@@ -104,7 +158,10 @@ class GradReducer:
 
     def _side_stream(self, device):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=device)
+            if os.environ.get('DVSOF_NO_STREAM_CLAIM') == '1':
+                self._side = torch.cuda.Stream(device=device)
+            else:
+                self._side = claim_streams(device)[1]
         return self._side
 
     def active(self):
@@ -120,10 +177,21 @@ class GradReducer:
             if after is not None:
                 after()
             return
-        self.bytes_reduced += flat.numel() * flat.element_size()
-        if flat.is_cuda and self._comm is not None:
+        if flat.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a captured step (capture.py): leave a MARK where the collective
+            # goes; the step executor issues it on every replay (csrc/exec.hip)
+            assert after is None, \
+                'the optimizer fused into the bucket hooks is not captured'
             from . import _lib
-            ready = torch.cuda.Event()
+            _lib.check(_lib.lib().dvsof_exec_mark(
+                1, self._marked, flat.data_ptr(), flat.numel(), _lib.stream()),
+                'dvsof_exec_mark')
+            self._marked += 1
+            return
+        self.bytes_reduced += flat.numel() * flat.element_size()
+        if flat.is_cuda and self._comm is not None and self._direct:
+            from . import _lib
+            ready = self._ready_event(flat)
             ready.record()
             side = self._side_stream(flat.device)
             with torch.cuda.stream(side):
@@ -137,12 +205,15 @@ class GradReducer:
             self._keep.append(flat)
             self._touched = True
         elif flat.is_cuda:
-            ready = torch.cuda.Event()
+            ready = self._ready_event(flat)
             ready.record()
             side = self._side_stream(flat.device)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG,
+                # (one rank: SUM is the same average, and RCCL then launches
+                # no scaled-copy kernel -- see csrc/comm.hip)
+                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.world > 1
+                                       else dist.ReduceOp.SUM,
                                        group=self.group, async_op=True)
                 if after is not None:
                     work.wait()          # the exchange stream waits for the collective
@@ -154,7 +225,21 @@ class GradReducer:
                                    group=self.group, async_op=True)
             self.pending.append((work, flat, True, after))
 
+    def _ready_event(self, flat):
+        """One event per bucket, recorded again every step (a bucket's
+        previous exchange has been joined before its gradients are rewritten)."""
+        ev = self._events.get(flat.data_ptr())
+        if ev is None:
+            ev = self._events[flat.data_ptr()] = torch.cuda.Event()
+        return ev
+
     def wait(self):
+        if self._marked and torch.cuda.is_current_stream_capturing():
+            from . import _lib      # the optimizer kernels come behind the exchange
+            _lib.check(_lib.lib().dvsof_exec_mark(2, 0, None, 0, _lib.stream()),
+                       'dvsof_exec_mark')
+            self._marked = 0
+            return
         for item in self.pending:
             work, flat, scale = item[:3]
             work.wait()          # NCCL: the current stream waits, not the host

@@ -566,7 +566,24 @@ class Predictor(nn.Module):
                         off += params[i].numel()
                 self._bucket_flat.append(
                     torch.empty(off, dtype=torch.float32, device=dev))
+            self._bucket_views = None
         return self._bucket_flat, self._bucket_slot
+
+    def attach_bucket_grads(self):
+        """``p.grad`` = the parameter's slice of its gradient bucket wherever
+        ``p.grad`` is unset.  After a captured micro-batch that only wrote or
+        accumulated gradients (capture.py roles 'first' / 'middle') this is
+        Python's view of what the replay did: the next eager micro-batch of
+        the same optimizer step then accumulates into the buckets."""
+        params = self.param_list()
+        flats, slot = self._buckets(params)
+        if getattr(self, '_bucket_views', None) is None:
+            self._bucket_views = [
+                flats[slot[i][0]][slot[i][1]:slot[i][1] + p.numel()]
+                .as_strided(p.shape, p.stride()) for i, p in enumerate(params)]
+        for p, v in zip(params, self._bucket_views):
+            if p.grad is None:
+                p.grad = v
 
     def _grad_targets(self, params):
         """-> (targets, finish): per-parameter tensors the backward writes

@@ -1,6 +1,6 @@
 """Stage timers (reference utils/timer.py).
 
-``FakeTimer`` mirrors utils/timer.py:19-49.  ``EventTimer`` replaces
+``FakeTimer`` serves the contract of utils/timer.py:19-49 with a null object.  ``EventTimer`` replaces
 ``SynchronizedWallClockTimer`` (utils/timer.py:52-132), which calls
 ``torch.cuda.synchronize()`` around every start/stop and so serialises the
 stream: here start/stop only record HIP events on the current stream and the
@@ -9,36 +9,31 @@ elapsed time is read back when ``log``/``elapsed`` is called.
 import torch
 
 
+class _Null:
+    """Accepts any call and does nothing; ``elapsed`` answers 0."""
+
+    def __getattr__(self, name):
+        return (lambda *a, **k: 0) if name == 'elapsed' else (lambda *a, **k: None)
+
+
 class FakeTimer:
-    class Timer:
-        def __init__(self, name):
-            pass
-
-        def start(self):
-            pass
-
-        def stop(self):
-            pass
-
-        def reset(self):
-            pass
-
-        def elapsed(self, reset=True):
-            return 0
+    """Timers switched off: the contract of the reference's no-op class
+    (utils/timer.py:19-49 -- ``timers(name).start() / .stop() / .reset() /
+    .elapsed()``, ``timers.log(names, ...)``, ``memory_usage()``) served by
+    one shared null object."""
+    _null = _Null()
 
     def __init__(self):
         self.timers = {}
 
     def __call__(self, name):
-        if name not in self.timers:
-            self.timers[name] = self.Timer(name)
-        return self.timers[name]
+        return self.timers.setdefault(name, self._null)
 
     @staticmethod
     def memory_usage():
         return ''
 
-    def log(self, names, normalizer=1.0, reset=True, memory_breakdown=False):
+    def log(self, *args, **kwargs):
         pass
 
 

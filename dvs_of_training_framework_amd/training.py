@@ -252,11 +252,14 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
 
     reducer:   parallel.GradReducer (data parallelism)
     log_every: write scalars every n-th optimizer step (1 = the reference)
-    capture:   replay the loop body as one hipGraph launch per step
-               (capture.CapturedTrainStep) once a batch signature has been
-               seen; raw events, no accumulation, no reducer -- anything else,
-               and any batch that does not fit the captured signature, runs
-               eagerly as before
+    capture:   replay the loop body from ONE C call per micro-batch
+               (capture.CapturedLoop / the step executor) once a batch
+               signature has been seen: raw events (wire or compact columns),
+               with or without accumulation, with or without a reducer (the
+               gradient exchange is then issued by the executor).  A batch of
+               another signature runs the same body eagerly; more events than
+               the captured buffers hold re-records at a larger capacity; if
+               recording fails training continues eagerly
     """
     if timers is None:
         on_gpu = torch.device(device).type == 'cuda'
@@ -265,6 +268,11 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
                        init_samples_passed)
     sums = ScaleSums()
     captured = None
+    if capture and is_raw and hasattr(optimizer, 'begin_capture') and \
+            not hasattr(optimizer, 'fused_active'):
+        from .capture import CapturedLoop
+        captured = CapturedLoop(model, evaluator, optimizer, weights, device,
+                                accumulation_steps, reducer)
     model.train()
     optimizer.zero_grad(set_to_none=True)
 
@@ -285,23 +293,13 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
             optimizer.fused_active = closes_step
 
         replayed = False
-        if capture and is_raw and accumulation_steps == 1 and reducer is None \
-                and hasattr(optimizer, 'begin_capture'):
-            if captured is None:
-                from .capture import CapturedTrainStep
-                # its constructor runs this batch's step eagerly, then records
-                captured = CapturedTrainStep(model, evaluator, optimizer,
-                                             weights, device, batch)
-                loss, terms, tags = (captured.first_loss, captured.first_terms,
-                                     captured.tags)
-                replayed = True
-            elif captured.fits(batch):
-                with _timed(timers, 'forward'):
-                    loss, terms = captured(batch)
-                tags, replayed = captured.tags, True
-            else:       # another signature: same step, eagerly
-                loss, terms, tags = captured.eager_step(batch, timers)
-                replayed = True
+        if captured is not None and captured.failed is None:
+            # the whole body of this micro-batch -- model, loss, backward and,
+            # when it closes the step, exchange + optimizer -- replayed,
+            # recorded (its first occurrence runs eagerly) or run eagerly
+            loss, terms, tags = captured.run(
+                batch, (clock.micro - 1) % accumulation_steps, timers)
+            replayed = True
         if not replayed:
             loss, terms, tags = process_minibatch(
                 model, batch, timers, device, is_raw, evaluator, weights)

@@ -32,6 +32,20 @@ def get_count_image(events, imsize, device='cuda'):
 
 WS_CLEAN = 1       # DVSOF_VOX_WS_CLEAN
 _WORKSPACES = {}
+_WS_ROUND = 1 << 16
+
+
+def _forget_workspace(ws):
+    """A call on ``ws`` failed: its control words may be dirty -- the next
+    call of that shape starts from a fresh, zero-filled workspace."""
+    for k in [k for k, v in _WORKSPACES.items() if v is ws]:
+        del _WORKSPACES[k]
+
+
+def _checked(rc, what, ws):
+    if rc != 0:
+        _forget_workspace(ws)
+    _lib.check(rc, what)
 
 
 def _workspace(n, B, C, H, W, device):
@@ -44,16 +58,24 @@ def _workspace(n, B, C, H, W, device):
     one stream are ordered; two streams voxelising the same shape concurrently
     must not share this cache (pass their own workspace through the C ABI)."""
     lib = _lib.lib()
-    nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
     control = lib.dvsof_voxelize_control_bytes(n, B, C, H, W)
     if control == 0:        # thread-per-event kernel: plain scratch
+        nbytes = lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W)
         return (torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device),
                 nbytes, 0)
-    key = (nbytes, control, str(device))
+    # sized and keyed by the event count ROUNDED UP (the kernels accept a larger
+    # buffer; the control region depends on B, C, H, W only): batches of
+    # varying event counts share one workspace instead of allocating and
+    # zero-filling one per distinct count
+    n_up = (n + _WS_ROUND - 1) // _WS_ROUND * _WS_ROUND
+    nbytes = max(lib.dvsof_voxelize_workspace_bytes(n_up, B, C, H, W),
+                 lib.dvsof_voxelize_workspace_bytes(n, B, C, H, W))
+    key = (n_up, control, B, C, H, W, str(device))
     ws = _WORKSPACES.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
-            # no warm-up call made one: graph-owned scratch + a memset node
+            # no warm-up call made one: graph-owned scratch, zero-filled by a
+            # kernel node of the capture (flags 0)
             return (torch.empty(nbytes, dtype=torch.uint8, device=device),
                     nbytes, 0)
         if len(_WORKSPACES) >= 16:      # a handful of shapes is the normal case:
@@ -83,11 +105,11 @@ def voxelize(events, t0, t1, B, C, H, W, debug=False):
         lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=t0.device)
     lib = _lib.lib()
     ws, nbytes, flags = _workspace(n, B, C, H, W, t0.device)
-    _lib.check(lib.dvsof_voxelize_tiled(
+    _checked(lib.dvsof_voxelize_tiled(
         x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(), s.data_ptr(),
         n, t0.contiguous().data_ptr(), t1.contiguous().data_ptr(), B, C, H, W,
         out.data_ptr(), _lib.ptr(bin0), _lib.ptr(lin0), _lib.ptr(ws), nbytes,
-        flags, _lib.stream()), 'dvsof_voxelize_tiled')
+        flags, _lib.stream()), 'dvsof_voxelize_tiled', ws)
     if debug:
         return out, bin0[:n], lin0[:n]
     return out
@@ -124,12 +146,12 @@ def voxelize_compact(events, t0, t1, B, C, H, W, debug=False):
         lin0 = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     lib = _lib.lib()
     ws, nbytes, flags = _workspace(n, B, C, H, W, dev)
-    _lib.check(lib.dvsof_voxelize_encoded(
+    _checked(lib.dvsof_voxelize_encoded(
         x.data_ptr(), y.data_ptr(), t.data_ptr(), p.data_ptr(),
         off.data_ptr(), n, t0.contiguous().data_ptr(),
         t1.contiguous().data_ptr(), B, C, H, W, out.data_ptr(),
         _lib.ptr(bin0), _lib.ptr(lin0), ws.data_ptr(), nbytes, flags,
-        _lib.stream()), 'dvsof_voxelize_encoded')
+        _lib.stream()), 'dvsof_voxelize_encoded', ws)
     if debug:
         return out, bin0[:n], lin0[:n]
     return out

@@ -85,10 +85,13 @@ int dvsof_voxelize_fwd(const int64_t *x, const int64_t *y, const float *t,
  * control words (bucket cursors, counters).  They must be ZERO when the call
  * starts executing and the call leaves them zero again (the kernels clean up
  * after themselves).  flags:
- *   0                   the call enqueues a memset of the control words first
+ *   0                   the call zero-fills the control words first (a fill
+ *                       KERNEL: no entry point of this library enqueues
+ *                       hipMemsetAsync, so a stream capture of it holds kernel
+ *                       nodes only)
  *   DVSOF_VOX_WS_CLEAN  the caller guarantees they are zero (zero-filled once,
  *                       then only used by calls of this family, one at a time
- *                       in stream order): no memset is enqueued
+ *                       in stream order): no fill is enqueued
  */
 #define DVSOF_VOX_WS_CLEAN 1
 size_t dvsof_voxelize_workspace_bytes(int64_t n_events, int B, int C, int H,
@@ -611,7 +614,33 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
  *                       cross-lane waits, kernel name (diagnostics)
  *   dvsof_exec_info     counts (any pointer may be NULL); lane_kernels[l] =
  *                       kernels of lane l for l < max_lanes
+ *
+ * Data parallelism and gradient accumulation (utils/training.py:156-167,
+ * utils/options.py:318-325) under the executor.  The exchange is not a kernel:
+ * while the step is captured the reducer leaves MARKS in the stream
+ * (dvsof_exec_mark) where the eager loop issues a collective / joins the
+ * exchange stream.  The executor never launches a mark; it acts on it:
+ *   DVSOF_MARK_BUCKET  (bucket, n): the exchange stream waits for the lane's
+ *                      progress, then dvsof_allreduce_bucket(comm, bucket, n)
+ *                      on the exchange stream
+ *   DVSOF_MARK_JOIN    the lane waits for the exchange stream (in front of
+ *                      the optimizer kernels)
+ *   dvsof_exec_set_comm  communicator (dvsof_comm_create) and exchange stream
+ *                      of the marks; comm NULL (or never set): marks are
+ *                      skipped -- one GPU.  Call before the first replay.
+ *   dvsof_exec_marks   number of marks found in the graph
+ *   dvsof_exec_node_arg  copies the first nbytes of kernel argument `arg` of
+ *                      node i (launch order) -- diagnostics: the pointer audit
+ *                      of capture.CapturedTrainStep.audit
+ * Every rank replays the same graph, so the collectives are issued in the
+ * same order everywhere.
  * ------------------------------------------------------------------ */
+#define DVSOF_MARK_BUCKET 1
+#define DVSOF_MARK_JOIN 2
+int dvsof_exec_mark(int kind, int index, float *bucket, size_t n, void *stream);
+int dvsof_exec_set_comm(void *exec, void *comm, void *exchange_stream);
+int dvsof_exec_marks(void *exec, int *n_marks);
+int dvsof_exec_node_arg(void *exec, int i, int arg, size_t nbytes, void *out);
 int dvsof_exec_create(void *graph, void *const *side_streams, int n_side,
                       void **exec);
 int dvsof_exec_info(void *exec, int *n_kernels, int *n_lanes, int *n_events,

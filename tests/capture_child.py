@@ -9,6 +9,18 @@ test runner down): runs one scenario and prints one JSON line.
   loop    training.train(capture=False) vs train(capture=True): logged scalars
   infer   OpticalFlow(graph=True): 30 replays back to back WITHOUT reading the
           result in between, then compared with the eager wrapper
+  big:<dtype>   executor vs eager at the BENCHMARK shape (B=8, 256x256x5,
+          65 536 events per sample): the Winograd / K-split / twins kernels
+          of that plan; with DVSOF_FORCE_DIST=1 in the environment both sides
+          run the data-parallel exchange (eager: torch.distributed on the
+          exchange stream; executor: marks -> ncclAllReduce from the C call)
+  accum[:dp]  train(accumulation_steps=3) eager vs capture=True (roles first /
+          middle / last), optionally under the 1-rank reducer
+  compact   train(capture=True) on compact (9 B/event) batches
+  grow    a batch with more events than the captured capacity: re-recorded
+  fail    recording raises: training continues eagerly, same results
+  audit   pointer audit of a captured step (every kernel argument pointer in
+          the graph pool or in an object the step keeps alive)
 """
 import json
 import sys
@@ -209,7 +221,205 @@ def scenario_infer():
             'graphs': len(graph._graphs)}
 
 
+def _dist():
+    """1-rank RCCL group when the test asks for it (DVSOF_FORCE_DIST=1)."""
+    import os
+    if os.environ.get('DVSOF_FORCE_DIST') != '1':
+        return None
+    from dvs_of_training_framework_amd import parallel
+    parallel.init_distributed('cuda')
+    red = parallel.GradReducer()
+    assert red.active()
+    return red
+
+
+def scenario_big(dtype):
+    from dvs_of_training_framework_amd.capture import CapturedTrainStep
+    from dvs_of_training_framework_amd.loss import unit_backward
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch
+    import time
+    B, H, W, steps = 8, 256, 256, 4
+    red = _dist()
+    batches = [synthetic.to_torch(synthetic.make_batch(900 + i, B, H, W, None), 'cuda')
+               for i in range(2)]
+
+    def eager():
+        model, opt, sched, init_losses = make(dtype=dtype)
+        model.predictor.reducer = red
+        ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+        losses = []
+        for i in range(steps):
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = process_minibatch(model, batches[i % 2], FakeTimer(), 'cuda', True, ev,
+                                           [0.5, 1, 1])
+            unit_backward(loss)
+            model.strict = False
+            if red is not None:
+                red.wait()
+            opt.step()
+            sched.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return [float(v) for v in losses], [p.detach().clone() for p in model.parameters()]
+
+    info = {}
+
+    def replayed():
+        model, opt, sched, init_losses = make(dtype=dtype)
+        model.predictor.reducer = red
+        ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+        caps, losses = {}, []
+        host = 0.0
+        for i in range(steps + 6):
+            k = i % 2
+            if k not in caps:
+                caps[k] = CapturedTrainStep(model, ev, opt, [0.5, 1, 1], 'cuda', batches[k],
+                                            bind=True, reducer=red)
+                loss = caps[k].first_loss
+            else:
+                t0 = time.perf_counter()
+                loss = caps[k]()[0]
+                if i >= steps + 2:      # calibrated, steady state
+                    host += time.perf_counter() - t0
+            sched.step()
+            if i < steps:
+                losses.append(loss.clone())
+            if i == steps - 1:
+                torch.cuda.synchronize()
+                weights = [p.detach().clone() for p in model.parameters()]
+        torch.cuda.synchronize()
+        x = caps[0].executor
+        info.update(kernels=x.kernels, lanes=x.lanes, lane_kernels=x.lane_kernels, marks=x.marks,
+                    host_ms_per_step=round(host / 4 * 1e3, 3))
+        for c in caps.values():
+            c.close()
+        return [float(v) for v in losses], weights
+    l_e, w_e = eager()
+    l_r, w_r = replayed()
+    return {'losses_equal': l_e == l_r, 'weights_equal': all(torch.equal(a, b) for a, b in zip(w_e, w_r)),
+            'eager': l_e, 'replayed': l_r, 'executor': info, 'dist': red is not None,
+            'max_weight_diff': max(float((a - b).abs().max()) for a, b in zip(w_e, w_r))}
+
+
+def _train_rows(data, capture, accum=1, red=None, steps=None, patch=None, compact=False):
+    from dvs_of_training_framework_amd import capture as cap_mod
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import train
+    B, H, W = data[0]['size'], data[0]['images'].shape[-2], data[0]['images'].shape[-1]
+    model, opt, sched, init_losses = make()
+    model.predictor.reducer = red
+    ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+    rows = []
+
+    class Log:
+        def add_scalar(self, t, v, x):
+            rows.append((t, float(v), x))
+    undo = patch(cap_mod) if patch and capture else None
+    info = {}
+    orig_close = cap_mod.CapturedLoop.close
+
+    def spy(self):
+        info.setdefault('roles', sorted(self.steps))
+        info['recaptures'] = self.recaptures
+        info['failed'] = str(self.failed) if self.failed else None
+        info['replays'] = info.get('replays', 0) + sum(s.replays for s in self.steps.values())
+        return orig_close(self)
+    cap_mod.CapturedLoop.close = spy
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            train(model, 'cuda', (synthetic.to_torch(b) for b in data), opt,
+                  steps or len(data) // accum, sched, Log(), ev, timers=FakeTimer(), capture=capture,
+                  max_events_per_batch=10 ** 7, accumulation_steps=accum, reducer=red)
+    finally:
+        cap_mod.CapturedLoop.close = orig_close
+        if undo:
+            undo()
+    torch.cuda.synchronize()
+    return rows, [p.detach().clone() for p in model.parameters()], info
+
+
+def _compare(data, **kw):
+    r0, w0, _ = _train_rows(data, False, **kw)
+    r1, w1, info = _train_rows(data, True, **kw)
+    return {'rows_equal': r0 == r1, 'n_rows': len(r0),
+            'weights_equal': all(torch.equal(a, b) for a, b in zip(w0, w1)), 'info': info,
+            'first_diff': next((a, b) for a, b in zip(r0, r1) if a != b) if r0 != r1 else None}
+
+
+def scenario_accum(dp=False):
+    B, H, W = 2, 64, 64
+    red = _dist() if dp else None
+    data = [unique_pixel_batch(300 + i, B, H, W, 4096 if i % 4 else 3100) for i in range(12)]
+    data[7] = unique_pixel_batch(307, 1, H, W, 4000)     # another signature, as a 'middle'
+    return _compare(data, accum=3, red=red)
+
+
+def scenario_compact():
+    from dvs_of_training_framework_amd import encoding
+    B, H, W = 2, 64, 64
+    data = []
+    for i in range(6):
+        b = unique_pixel_batch(400 + i, B, H, W, 4096 if i % 2 else 3300)
+        ev = b['events']
+        counts = np.bincount(ev['sample_index'], minlength=B)
+        b['events'] = {'x': ev['x'].astype(np.int16), 'y': ev['y'].astype(np.int16),
+                       'timestamp': ev['timestamp'].astype(np.float32),
+                       'polarity': (ev['polarity'] > 0),
+                       'sample_event_offsets': np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)}
+        data.append(b)
+    return _compare(data)
+
+
+def scenario_grow():
+    B, H, W = 2, 64, 64
+    # events per sample; capacities 8192 -> 16384 -> 32768 (all on the tiled
+    # voxeliser, which is bitwise reproducible whatever the event order)
+    counts = [2100, 4000, 6000, 5000, 2100, 12000]
+    data = [synthetic.make_batch(500 + i, B, H, W, c) for i, c in enumerate(counts)]
+    return _compare(data)
+
+
+def scenario_fail():
+    B, H, W = 2, 64, 64
+    data = [unique_pixel_batch(600 + i, B, H, W, 4096) for i in range(5)]
+
+    def patch(cap_mod):
+        orig = cap_mod.CapturedTrainStep._record
+
+        def boom(self, executor):
+            raise RuntimeError('injected: dvsof_exec_create refused the graph')
+        cap_mod.CapturedTrainStep._record = boom
+        return lambda: setattr(cap_mod.CapturedTrainStep, '_record', orig)
+    return _compare(data, patch=patch)
+
+
+def scenario_audit():
+    from dvs_of_training_framework_amd.capture import CapturedTrainStep
+    B, H, W = 2, 64, 64
+    model, opt, sched, init_losses = make()
+    ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
+    batch = synthetic.to_torch(unique_pixel_batch(700, B, H, W, 4096), 'cuda')
+    step = CapturedTrainStep(model, ev, opt, [0.5, 1, 1], 'cuda', batch, event_capacity=8192)
+    ok = step.audit()
+    # the bug class: drop an eager object the graph points at from the keep list
+    step._keep = [k for k in step._keep if k is not step.static]
+    static_ptrs = step.static
+    step.static = None
+    bad = step.audit()
+    step.static = static_ptrs
+    step.close()
+    return {'ok': ok, 'bad': {k: v for k, v in bad.items() if k != 'unheld'},
+            'bad_unheld': len(bad['unheld'])}
+
+
 if __name__ == '__main__':
+    name, _, arg = sys.argv[1].partition(':')
     out = {'train': scenario_train, 'train_graph': lambda: scenario_train(False),
-           'loop': scenario_loop, 'bind': scenario_bind, 'infer': scenario_infer}[sys.argv[1]]()
+           'loop': scenario_loop, 'bind': scenario_bind, 'infer': scenario_infer,
+           'big': lambda: scenario_big(arg or 'f32'), 'accum': lambda: scenario_accum(arg == 'dp'),
+           'compact': scenario_compact, 'grow': scenario_grow, 'fail': scenario_fail,
+           'audit': scenario_audit}[name]()
     print(json.dumps(out), flush=True)

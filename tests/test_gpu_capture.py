@@ -4,6 +4,7 @@ back without host synchronisation.  Every scenario runs in a child process
 (tests/capture_child.py): a GPU fault there fails one test instead of killing
 the runner."""
 import json
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -14,9 +15,14 @@ pytestmark = pytest.mark.gpu
 CHILD = Path(__file__).resolve().parent / 'capture_child.py'
 
 
-def run(scenario):
+def run(scenario, dist=False):
+    env = dict(os.environ)
+    if dist:        # a 1-rank nccl (= RCCL) group in the child: the real exchange path
+        env.update(DVSOF_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', RANK='0', WORLD_SIZE='1',
+                   LOCAL_RANK='0', MASTER_PORT=str(29500 + os.getpid() % 2000),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, str(CHILD), scenario], capture_output=True, text=True,
-                         timeout=600)
+                         timeout=900, env=env)
     assert out.returncode == 0, (out.returncode, out.stderr[-3000:])
     return json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -69,3 +75,77 @@ def test_inference_graph_replays_back_to_back_without_host_sync():
     r = run('infer')
     assert r['graphs'] == 1
     assert r['max_diff'] <= 1e-5 * max(1.0, r['peak']), r
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16s'])
+def test_executor_equals_eager_at_the_benchmark_shape(dtype):
+    """B = 8, 256x256x5, 65 536 events per sample -- the plan the driver's
+    bench line rides on (Winograd residual layers, K-split weight gradients,
+    in bf16s the twins kernels): executor replays == eager steps, bit for bit."""
+    r = run(f'big:{dtype}')
+    assert r['losses_equal'] and r['weights_equal'], r
+    x = r['executor']
+    assert x['lanes'] == 2 and x['kernels'] > 90 and x['marks'] == 0, x
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16s'])
+def test_executor_issues_the_gradient_exchange_under_data_parallelism(dtype):
+    """The same comparison inside a 1-rank RCCL group: the eager loop hands
+    its 8 buckets to torch.distributed on the exchange stream, the captured
+    step carries 8 bucket marks + 1 join mark and the executor calls
+    ncclAllReduce (dvsof_allreduce_bucket) between its launches.  Average over
+    one rank is the identity: bit-identical, and the host stays under 0.8 ms
+    per step."""
+    r = run(f'big:{dtype}', dist=True)
+    assert r['dist'] and r['losses_equal'] and r['weights_equal'], r
+    x = r['executor']
+    assert x['marks'] == 9 and x['lanes'] == 2, x
+    assert x['host_ms_per_step'] <= 0.8, x
+
+
+@pytest.mark.parametrize('dp', [False, True])
+def test_train_loop_captures_gradient_accumulation(dp):
+    """train(accumulation_steps=3, capture=True): the roles first / middle /
+    last are recorded as they are met (utils/training.py:156-167); a batch of
+    another signature in the middle of a step runs eagerly into the same
+    buckets.  Same scalars and weights as the eager loop -- also with the
+    1-rank reducer, whose exchange happens on the closing micro-batch only."""
+    r = run('accum:dp' if dp else 'accum', dist=dp)
+    assert r['n_rows'] > 0 and r['rows_equal'] and r['weights_equal'], r
+    assert r['info']['roles'] == ['first', 'last', 'middle'] and r['info']['replays'] >= 5, r
+
+
+def test_train_loop_captures_compact_event_batches():
+    """--capture with --compact-events (round-2 advisor finding: KeyError on
+    the first compact batch): the 9 B/event columns + sample_event_offsets are
+    staged and padded like the wire columns."""
+    r = run('compact')
+    assert r['n_rows'] > 0 and r['rows_equal'] and r['weights_equal'], r
+    assert r['info']['replays'] >= 4 and r['info']['failed'] is None, r
+
+
+def test_captured_loop_re_records_when_a_batch_brings_more_events():
+    r = run('grow')
+    assert r['rows_equal'] and r['weights_equal'], r
+    assert r['info']['recaptures'] == 2, r
+
+
+def test_train_loop_survives_a_failed_recording():
+    """dvsof_exec_create refusing a graph (or any error while recording) must
+    not abort training: the micro-batch the constructor ran eagerly counts,
+    the rest of the run is eager."""
+    r = run('fail')
+    assert r['rows_equal'] and r['weights_equal'], r
+    assert r['info']['failed'] and 'injected' in r['info']['failed'], r
+
+
+def test_pointer_audit_of_a_captured_step():
+    """Every pointer argument of the captured kernel nodes lies in the graph's
+    pool or in an object the step holds; dropping one held object (the static
+    input buffers) from the keep list makes the audit name the kernels that
+    read it."""
+    r = run('audit')
+    ok = r['ok']
+    assert ok['audited'] >= 80 and ok['pointers'] > 300 and not ok['unheld'], ok
+    assert len(ok['foreign']) <= 4, ok['foreign']      # the ATen gathers of the step
+    assert r['bad_unheld'] > 0, r

@@ -160,6 +160,77 @@ def test_config4_step_ranger_bf16_one_million_events_compact():
     assert list(tags) == ['64x64', '128x128', '256x256', '512x512']
 
 
+# ------------------------------------------------------------------ configs[3]
+def test_config3_step_as_configured_vs_the_cpu_port():
+    """BASELINE.json configs[3] per GPU, as configured: EV_FlowNet on
+    480x640x9-bin (MVSEC-shaped) frames, batch 16 over 4 GPUs = 4 per GPU,
+    H*W = 307 200 events per sample, multi-scale warp loss, f32.
+    One whole training step against the CPU port at the SAME batch: voxel
+    indices bit-exact, grid sums 1e-4, flows 1e-3 of the peak per scale, the
+    twelve loss terms and the loss 1e-3, parameter gradients against ATen
+    autograd on the field norm (the pin of the full-size predictor test), and
+    the AdamW update moves the weights."""
+    from dvs_of_training_framework_amd import voxel
+    from dvs_of_training_framework_amd.loss import init_losses
+    from dvs_of_training_framework_amd.net import Model
+    from dvs_of_training_framework_amd.optim import FusedAdamW
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import process_minibatch
+    B, C, H, W = 4, 9, 480, 640
+    n = H * W
+    b_np = synthetic.make_batch(1234, B, H, W, n)
+    batch = synthetic.to_torch(b_np, DEV)
+    torch.manual_seed(3)
+    model = Model(DEV, event_representation_depth=C)
+    model.train()
+    opt = FusedAdamW(model.predictor.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+    ev = init_losses((H, W), B, model, DEV, sequence_length=1)
+    before = {k: v.detach().cpu().clone() for k, v in model.predictor.state_dict().items()}
+
+    # voxeliser: integer parts bit-exact against the C oracle
+    t0 = torch.zeros(B, device=DEV)
+    t1 = torch.full((B,), synthetic.WINDOW, device=DEV)
+    grid, bin0, lin0 = voxel.voxelize(batch['events'], t0, t1, B, C, H, W, debug=True)
+    want, obin, olin = orc.voxelize(b_np['events'], np.zeros(B, np.float32),
+                                    np.full(B, synthetic.WINDOW, np.float32), B, C, H, W)
+    assert np.array_equal(bin0.cpu().numpy(), obin)
+    assert np.array_equal(lin0.cpu().numpy(), olin)
+    np.testing.assert_allclose(grid.cpu().numpy(), want, atol=1e-4, rtol=1e-4)
+    del grid, bin0, lin0
+
+    loss, terms, tags, info = process_minibatch(model, batch, FakeTimer(), DEV, True, ev,
+                                                [0.5, 1, 1], return_prediction=True)
+    assert list(tags) == ['60x80', '120x160', '240x320', '480x640']
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().clone() for k, p in model.predictor.named_parameters()}
+    got_terms = np.array(terms.host())
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(before['enc.0.conv.weight'],
+                           model.predictor.state_dict()['enc.0.conv.weight'].cpu())
+
+    # the CPU port of the same step (oracle/: C voxeliser + loss, ATen f32 predictor)
+    state = {k: v.clone().requires_grad_(True) for k, v in before.items()}
+    flows = ref_predictor(state, torch.from_numpy(want))
+    o_terms, o_loss, o_grads = orc.losses(
+        [f.detach().numpy() for f in flows], b_np['timestamps'].reshape(B, 2), np.arange(B),
+        b_np['images'], b_np['timestamps'], b_np['sample_idx'])
+    for f, r in zip(info['prediction'], flows):
+        r = r.detach()
+        assert float((f.detach().cpu() - r).abs().max()) <= 1e-3 * float(r.abs().max())
+    np.testing.assert_allclose(got_terms, o_terms, rtol=1e-3, atol=1e-7)
+    assert abs(float(loss.detach()) - o_loss) <= 1e-3 * abs(o_loss)
+    torch.autograd.backward(flows, [torch.from_numpy(g) for g in o_grads])
+    for k, g in grads.items():
+        r = state[k].grad
+        assert bool(torch.isfinite(g).all()), k
+        # field norm: see test_predictor_full_size_vs_float64_and_determinism (ReLU-mask
+        # flips of activations within 1e-6 of zero) and DESIGN section 2 (loss gradients
+        # where |warped - prev| < 1e-3)
+        assert float((g - r).norm()) <= 1e-2 * float(r.norm()) + 1e-9, \
+            (k, float((g - r).norm()) / float(r.norm()))
+
+
 # ----------------------------------------------------------- DP equivalence
 def _split(b_np, B, lo, hi):
     ev = b_np['events']
