@@ -95,6 +95,8 @@ def parse():
     p.add_argument('--no-other-modes', action='store_true',
                    help='skip the short bf16x3 / bf16 runs reported beside the fp32 headline')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-train-loop', action='store_true',
+                   help='skip the train() runs fed from host memory (train_loop in the JSON line)')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--cpu-samples', type=int, default=2)
     return p.parse_args()
@@ -373,19 +375,37 @@ def measure_roofline(h, step_ms, steps=3):
     tot = [sum(v[i] for v in agg.values()) for i in range(4)]
     tot_alone = [sum(v[i] for v in alone.values()) for i in range(4)]
     vox_b, loss_b = hbm_bytes(h.a)
+    # HBM-bound call paths: algorithmic bytes / device time of the WHOLE
+    # call path, back to back with the GPU to itself (enqueued behind a spin kernel so
+    # that the host runs ahead: the paths are shorter than their enqueue from Python, so
+    # an event pair around one call inside the step would time the host, not the GPU)
     hbm = {}
     for key, nbytes in (('voxelise', vox_b), ('warp+loss', loss_b)):
-        t = hbm_t[key]
-        if t > 0:
+        ta = hbm_alone.get(key, 0.0)
+        if ta > 0:
             hbm[key] = {'bound': 'hbm', 'algorithmic_bytes': nbytes,
-                        'call_path_us': round(t * 1e6, 2),
-                        'achieved': round(nbytes / t / 1e9, 1), 'peak': PEAK_HBM_TBS * 1e3,
-                        'unit': 'GB/s', 'frac': round(nbytes / t / 1e12 / PEAK_HBM_TBS, 4)}
-            ta = hbm_alone.get(key, 0.0)
-            if ta > 0:      # the same call path back to back with nothing else on the GPU
-                hbm[key]['alone'] = {'call_path_us': round(ta * 1e6, 2),
-                                     'achieved': round(nbytes / ta / 1e9, 1),
-                                     'frac': round(nbytes / ta / 1e12 / PEAK_HBM_TBS, 4)}
+                        'call_path_us': round(ta * 1e6, 2),
+                        'achieved': round(nbytes / ta / 1e9, 1), 'peak': PEAK_HBM_TBS * 1e3,
+                        'unit': 'GB/s', 'frac': round(nbytes / ta / 1e12 / PEAK_HBM_TBS, 4),
+                        'shape': f'B={h.a.batch} {h.a.height}x{h.a.width}x{h.a.bins} (the benchmark step)'}
+    # ... and where bandwidth can show: at batch 8 both paths are one round of resident
+    # workgroups (a chain of dependent memory round trips)
+    try:
+        from tools import hbm_bench
+        large = {}
+        for name, fn, args in (
+                ('voxelise B=64 256x256x5, 65536 ev/sample', hbm_bench.voxel_case, (64, 5, 256, 256, 65536)),
+                ('voxelise B=4 512x512x12, 1M ev/sample', hbm_bench.voxel_case, (4, 12, 512, 512, 1_000_000)),
+                ('warp+loss B=64 256x256', hbm_bench.loss_case, (64, 256, 256)),
+                ('warp+loss B=16 480x640', hbm_bench.loss_case, (16, 480, 640))):
+            us, nbytes = fn(*args)
+            large[name] = {'algorithmic_bytes': int(nbytes), 'call_path_us': round(us, 1),
+                           'achieved': round(nbytes / us / 1e3, 1), 'unit': 'GB/s',
+                           'frac': round(nbytes / us / 1e6 / PEAK_HBM_TBS, 4)}
+            torch.cuda.empty_cache()
+        hbm['large_shapes'] = large
+    except Exception as e:      # noqa: BLE001 -- a diagnostics table, never the headline
+        hbm['large_shapes'] = {'error': f'{type(e).__name__}: {e}'}
     roof = {
         # dominant kernel group: FLOPs the matrix cores EXECUTE per launch (the
         # sub-pixel / phase / Winograd forms issue fewer than the layer's
@@ -468,6 +488,79 @@ def cpu_baseline(a):
                       f'{a.height}x{a.width}x{a.bins}, {dt:.1f} s, '
                       f'torch {cores} threads (ATen predictor + AdamW) + scalar '
                       'single-thread C voxeliser/loss'}
+
+
+def train_loop_rates(a, device, steps=120, warm=30):
+    """samples/s of training.train() FED FROM HOST MEMORY -- the loop the
+    reference runs (utils/training.py:138-167) including its host-to-device leg
+    (:45-56), which the headline above leaves out (inputs resident in HBM):
+
+      feeder + captured  feed.DeviceFeeder (copy stream, two device slots, the
+                         copy of batch n+1 under step n) + train(capture=True)
+                         (one captured step bound to each slot);
+                         'wire': the int64 columns of the reference's collate
+                         (36 B/event moved: element_index is read by no kernel),
+                         'compact': the encoded 9 B/event columns
+                         (utils/dataset.py:286-289) voxelised directly
+      reference leg      train() on pageable host batches, tensor.to(device) on
+                         the compute stream at the top of every step, every
+                         kernel enqueued from Python
+
+    Host batches are pinned (DataLoader(pin_memory=True), utils/dataloader.py:
+    103-108) and cycle through a pool of 4."""
+    from dvs_of_training_framework_amd import encoding, synthetic
+    from dvs_of_training_framework_amd.feed import DeviceFeeder
+    from dvs_of_training_framework_amd.loss import init_losses
+    from dvs_of_training_framework_amd.net import Model
+    from dvs_of_training_framework_amd.optim import FusedAdamW
+    from dvs_of_training_framework_amd.timer import FakeTimer
+    from dvs_of_training_framework_amd.training import train
+
+    def pin(v):
+        if isinstance(v, dict):
+            return {k: pin(x) for k, x in v.items()}
+        return v.pin_memory() if torch.is_tensor(v) else v
+    wire = [synthetic.to_torch(synthetic.make_batch(4321 + i, a.batch, a.height, a.width, a.events))
+            for i in range(4)]
+
+    def as_compact(b):
+        enc = encoding.encode_batch(b['events'], b['timestamps'], b['sample_idx'], b['images'],
+                                    {}, a.batch)
+        return dict(b, events=encoding.compact_events(enc))
+    pools = {'wire': wire, 'compact': [as_compact(b) for b in wire]}
+
+    def run(pool, feeder, capture):
+        torch.manual_seed(1234)
+        model = Model(device, event_representation_depth=a.bins, compute_dtype=a.dtype)
+        opt = FusedAdamW(model.predictor.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 2 ** (-s / 100000))
+        ev = init_losses((a.height, a.width), a.batch, model, device, sequence_length=1)
+        host = [pin(b) for b in pool] if feeder else pool
+        loader = ({k: (dict(v) if isinstance(v, dict) else v) for k, v in host[i % len(host)].items()}
+                  for i in range(steps + 8))
+        fd = DeviceFeeder(loader, device) if feeder else None
+        mark = {}
+
+        def clock(step, samples):
+            if step == warm:
+                torch.cuda.synchronize()
+                mark['t0'] = time.perf_counter()
+        train(model, device, loader if fd is None else fd, opt, steps, sched, None, ev, timers=FakeTimer(),
+              hooks={'clock': clock}, capture=capture, log_every=10 ** 9,
+              max_events_per_batch=10 ** 9)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - mark['t0']
+        out = {'samples_per_s': round(a.batch * (steps - warm) / dt, 1),
+               'ms_per_step': round(dt / (steps - warm) * 1e3, 3)}
+        if fd is not None:
+            out['h2d_MB_per_step'] = round(fd.bytes_moved / fd.batches / 1e6, 2)
+        return out
+    return {'feeder+captured': {'wire': run(pools['wire'], True, True),
+                                'compact': run(pools['compact'], True, True)},
+            'reference leg (.to(device) per step, eager launches)': {
+                'wire': run(pools['wire'], False, False)},
+            'steps': steps - warm, 'batch': a.batch,
+            'note': 'training.train() fed from host memory; see bench.py:train_loop_rates'}
 
 
 def main():
@@ -581,6 +674,11 @@ def main():
                           'path); bf16 = f32 storage, operands rounded once; bf16s = bf16 twins of '
                           'activations / gradients / weight forms streamed through LDS')
         out['other_modes'] = others
+    if rank == 0 and world == 1 and not a.no_train_loop:
+        if 'h' in dir():
+            h.suspend_graph()
+            del h
+        out['train_loop'] = train_loop_rates(a, device)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a)

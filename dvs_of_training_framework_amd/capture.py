@@ -223,6 +223,7 @@ class CapturedTrainStep:
         n = ev['x'].numel()
         dev = self.device
         self.bound = example_batch if bind else None
+        self.slot = example_batch.get('slot') if bind else None   # feed.DeviceFeeder buffers
         self.keys, self.per_event = _event_layout(ev)
         if share is not None:
             assert not bind and share.fits(example_batch)
@@ -372,7 +373,9 @@ class CapturedTrainStep:
         """-> (loss, terms): 0-dim tensor and a TermReadback, both reading the
         graph's static outputs (valid until the next call).  ``batch=None`` (or
         the bound batch itself): the input buffers already hold the batch."""
-        if batch is not None and batch is not self.bound and batch is not self.static:
+        bound = batch is self.bound or batch is self.static or \
+            (self.slot is not None and batch is not None and batch.get('slot') == self.slot)
+        if batch is not None and not bound:
             assert self.fits(batch), 'batch does not match the captured signature'
             self._load(batch)
         if not getattr(self.optimizer, '_use_dyn', False):
@@ -422,16 +425,51 @@ class CapturedLoop:
         self.args = (model, evaluator, optimizer, weights, device)
         self.accum, self.reducer, self.executor = accumulation_steps, reducer, executor
         self.event_capacity = event_capacity
-        self.steps = {}
+        self.steps = {}         # role -> step over this loop's own input buffers
+        self.bound = {}         # (role, slot, generation) -> step bound to a feeder slot
         self.failed = None      # CaptureFailed of the role that could not be recorded
         self.recaptures = 0
 
     def any(self):
         return next(iter(self.steps.values()), None)
 
+    def _failed(self, e, role):
+        import warnings
+        warnings.warn(f'captured step ({role}) could not be recorded, '
+                      f'training continues eagerly: {e}')
+        self.failed = e
+        self.close()
+        if role in ('full', 'last'):    # the eager loop's zero_grad after its step
+            self.args[2].zero_grad(set_to_none=True)
+        return e.loss, e.terms, e.tags
+
+    def _run_bound(self, batch, role, timers):
+        """A feed.DeviceFeeder batch: its slot's device buffers ARE the input
+        buffers of the step (bind=True), one captured step per (role, slot)."""
+        index, generation = batch['slot']
+        for k in [k for k in self.bound if k[1] == index and k[2] != generation]:
+            self.bound.pop(k).close()       # that slot's buffers were re-allocated
+        key = (role, index, generation)
+        step = self.bound.get(key)
+        if step is None and self.failed is None:
+            try:
+                step = self.bound[key] = CapturedTrainStep(
+                    *self.args, batch, executor=self.executor, bind=True,
+                    reducer=self.reducer, role=role, accumulation_steps=self.accum)
+            except CaptureFailed as e:
+                return self._failed(e, role)
+            return step.first_loss, step.first_terms, step.tags
+        if step is not None:
+            with _timed(timers or FakeTimer(), 'forward'):
+                loss, terms = step(batch)
+            return loss, terms, step.tags
+        return self._eager(role, batch, timers)
+
     def run(self, batch, micro_in_step, timers=None):
         """-> (loss, terms, tags) of this micro-batch."""
         role = role_of(micro_in_step, self.accum)
+        if batch.get('slot') is not None:
+            return self._run_bound(batch, role, timers)
         step, lead = self.steps.get(role), self.any()
         if lead is not None and lead.same_signature(batch) and not lead.fits(batch):
             # more events than the buffers hold: every role is recorded again
@@ -448,14 +486,7 @@ class CapturedLoop:
                     reducer=self.reducer, role=role, accumulation_steps=self.accum,
                     share=lead)
             except CaptureFailed as e:
-                import warnings
-                warnings.warn(f'captured step ({role}) could not be recorded, '
-                              f'training continues eagerly: {e}')
-                self.failed = e
-                self.close()
-                if role in ('full', 'last'):    # the eager loop's zero_grad after its step
-                    self.args[2].zero_grad(set_to_none=True)
-                return e.loss, e.terms, e.tags
+                return self._failed(e, role)
             return step.first_loss, step.first_terms, step.tags
         if step is not None and step.fits(batch):
             with _timed(timers or FakeTimer(), 'forward'):
@@ -466,7 +497,8 @@ class CapturedLoop:
     def _eager(self, role, batch, timers):
         """Another signature (or recording is off): the eager body in this
         role, on the same buckets."""
-        proto = self.steps.get(role)
+        proto = self.steps.get(role) or next(
+            (v for k, v in self.bound.items() if k[0] == role), None)
         if proto is not None:
             return proto.eager_step(batch, timers)
         body = _EagerBody(*self.args, self.reducer, role, self.accum)
@@ -480,9 +512,9 @@ class CapturedLoop:
         return out
 
     def close(self):
-        for s in self.steps.values():
+        for s in list(self.steps.values()) + list(self.bound.values()):
             s.close()
-        self.steps = {}
+        self.steps, self.bound = {}, {}
 
 
 class _EagerBody(CapturedTrainStep):

@@ -281,7 +281,8 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
         if clock.finished():
             break
         if is_raw:
-            num_events = batch['events']['x'].numel()
+            # (a feed.DeviceFeeder batch is padded to its slot's capacity)
+            num_events = batch.get('num_events', batch['events']['x'].numel())
             if num_events > max_events_per_batch:
                 clock.skip(num_events, batch)
                 continue

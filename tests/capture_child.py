@@ -18,6 +18,7 @@ test runner down): runs one scenario and prints one JSON line.
           middle / last), optionally under the 1-rank reducer
   compact   train(capture=True) on compact (9 B/event) batches
   grow    a batch with more events than the captured capacity: re-recorded
+  feed[:k]  train() fed by feed.DeviceFeeder (k = accumulation steps)
   fail    recording raises: training continues eagerly, same results
   audit   pointer audit of a captured step (every kernel argument pointer in
           the graph pool or in an object the step keeps alive)
@@ -302,7 +303,7 @@ def scenario_big(dtype):
             'max_weight_diff': max(float((a - b).abs().max()) for a, b in zip(w_e, w_r))}
 
 
-def _train_rows(data, capture, accum=1, red=None, steps=None, patch=None, compact=False):
+def _train_rows(data, capture, accum=1, red=None, steps=None, patch=None, compact=False, feed=False):
     from dvs_of_training_framework_amd import capture as cap_mod
     from dvs_of_training_framework_amd.timer import FakeTimer
     from dvs_of_training_framework_amd.training import train
@@ -323,14 +324,27 @@ def _train_rows(data, capture, accum=1, red=None, steps=None, patch=None, compac
         info.setdefault('roles', sorted(self.steps))
         info['recaptures'] = self.recaptures
         info['failed'] = str(self.failed) if self.failed else None
-        info['replays'] = info.get('replays', 0) + sum(s.replays for s in self.steps.values())
+        info['replays'] = info.get('replays', 0) + sum(
+            s.replays for s in list(self.steps.values()) + list(self.bound.values()))
         return orig_close(self)
     cap_mod.CapturedLoop.close = spy
     try:
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            train(model, 'cuda', (synthetic.to_torch(b) for b in data), opt,
+            loader = (synthetic.to_torch(b) for b in data)
+            if feed:
+                from dvs_of_training_framework_amd.feed import DeviceFeeder
+
+                def pinned_every_other(it):     # pinned sources go as they are, pageable ones
+                    for i, b in enumerate(it):  # through the slot's staging buffers
+                        if i % 2:
+                            b = {k: ({c: t.pin_memory() for c, t in v.items()} if isinstance(v, dict)
+                                     else v.pin_memory() if torch.is_tensor(v) else v) for k, v in b.items()}
+                        yield b
+                loader = DeviceFeeder(pinned_every_other(loader), 'cuda')
+                info['feeder'] = loader
+            train(model, 'cuda', loader, opt,
                   steps or len(data) // accum, sched, Log(), ev, timers=FakeTimer(), capture=capture,
                   max_events_per_batch=10 ** 7, accumulation_steps=accum, reducer=red)
     finally:
@@ -338,7 +352,24 @@ def _train_rows(data, capture, accum=1, red=None, steps=None, patch=None, compac
         if undo:
             undo()
     torch.cuda.synchronize()
+    if 'feeder' in info:
+        f = info.pop('feeder')
+        info['fed_batches'], info['fed_bytes'] = f.batches, f.bytes_moved
     return rows, [p.detach().clone() for p in model.parameters()], info
+
+
+def scenario_feed(accum):
+    """train() fed by feed.DeviceFeeder (copy stream, two slots, captured steps
+    bound to the slots) against the plain loop with .to(device) per batch."""
+    B, H, W = 2, 64, 64
+    counts = [2100, 4000, 3000, 4096, 2500, 4096, 7000, 2200]    # 7000: the slots grow
+    data = [synthetic.make_batch(800 + i, B, H, W, c) for i, c in enumerate(counts)]
+    r0, w0, _ = _train_rows(data, False, accum=accum)
+    r1, w1, i1 = _train_rows(data, False, accum=accum, feed=True)
+    r2, w2, i2 = _train_rows(data, True, accum=accum, feed=True)
+    same = lambda a, b: all(torch.equal(u, v) for u, v in zip(a, b))  # noqa: E731
+    return {'n_rows': len(r0), 'eager_feed_equal': r0 == r1 and same(w0, w1),
+            'capture_feed_equal': r0 == r2 and same(w0, w2), 'eager': i1, 'capture': i2}
 
 
 def _compare(data, **kw):
@@ -420,6 +451,6 @@ if __name__ == '__main__':
     out = {'train': scenario_train, 'train_graph': lambda: scenario_train(False),
            'loop': scenario_loop, 'bind': scenario_bind, 'infer': scenario_infer,
            'big': lambda: scenario_big(arg or 'f32'), 'accum': lambda: scenario_accum(arg == 'dp'),
-           'compact': scenario_compact, 'grow': scenario_grow, 'fail': scenario_fail,
+           'compact': scenario_compact, 'grow': scenario_grow, 'feed': lambda: scenario_feed(int(arg or 1)), 'fail': scenario_fail,
            'audit': scenario_audit}[name]()
     print(json.dumps(out), flush=True)

@@ -149,3 +149,16 @@ def test_pointer_audit_of_a_captured_step():
     assert ok['audited'] >= 80 and ok['pointers'] > 300 and not ok['unheld'], ok
     assert len(ok['foreign']) <= 4, ok['foreign']      # the ATen gathers of the step
     assert r['bad_unheld'] > 0, r
+
+
+@pytest.mark.parametrize('accum', [1, 2])
+def test_device_feeder_overlaps_the_host_to_device_copy(accum):
+    """feed.DeviceFeeder: batches copied into two slots on a copy stream while
+    the previous step runs (pinned sources directly, pageable ones through
+    pinned staging), padded with x = y = -1, slots re-allocated when a batch
+    outgrows them.  The eager loop and the captured loop (one step bound to
+    each slot, no staging copy) both reproduce the plain .to(device) loop bit
+    for bit (utils/training.py:45-56 is the leg this replaces)."""
+    r = run(f'feed:{accum}')
+    assert r['n_rows'] > 0 and r['eager_feed_equal'] and r['capture_feed_equal'], r
+    assert r['capture']['fed_batches'] == 8 and r['capture']['replays'] >= 2, r

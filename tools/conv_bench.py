@@ -20,6 +20,7 @@ def main():
     p.add_argument('--width', type=int, default=256)
     p.add_argument('--bins', type=int, default=5)
     p.add_argument('--reps', type=int, default=3)
+    p.add_argument('--dtype', default='f32', choices=('f32', 'bf16', 'bf16x3', 'bf16s'))
     a = p.parse_args()
     a.events, a.pool = None, 1
     dev = torch.device('cuda', 0)
