@@ -51,6 +51,8 @@ def kernel_name(family, tile, gen, wino=0):
         ng = (wino + 2) ** 2
         gemm = 'gconv2_kernel<2,2,1,1,1,4,1,0,1>' if family == 'gconv' else 'wgrad2_kernel<2,2,1,1,0,1>'
         return f'winograd F({wino}x{wino},3x3) {family}: wino_*_kernel + {gemm} 64x64 x{ng}'
+    if gen == 3:    # csrc/first.hip: planar voxel input, K = 9 C
+        return 'first_fwd_kernel 4x32 px' if family == 'gconv' else 'first_wgrad_kernel + reduce'
     if gen == 0:
         return 'wgrad_flat_kernel (VALU, flat members)'
     # (gconv2 instantiations carry two more template arguments in rocprof

@@ -25,7 +25,22 @@ int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *gout, float
                       int H, int W, int C, int N, int mfma_bf16, float *ws, size_t ws_floats,
                       hipStream_t st);
 
+// first.hip: the first encoder layer (planar voxel input, K = 9 C) as kernels of its own
+bool first_layer_shape(int nsrc, int planar, int C, int Cout, int H, int W, int ksize, int stride,
+                       int pad, int upsample);
+int first_fwd_launch(const float *x, int B, int C, int H, int W, const float *w, const float *bias,
+                     int act, float *y, float *z, unsigned short *y16, hipStream_t st);
+size_t first_wgrad_workspace_floats(int B, int C, int H, int W);
+int first_wgrad_launch(const float *x, int B, int C, int H, int W, const float *gout, float *dW,
+                       float *dbias, float *ws, size_t ws_floats, hipStream_t st);
+
 namespace {
+
+bool is_first_layer(const dvsof_conv_desc_t *d)
+{
+    return first_layer_shape(d->nsrc, d->src[0].layout == DVSOF_NCHW, d->src[0].C, d->Cout, d->H, d->W,
+                             d->ksize, d->stride, d->pad, d->upsample) && !d->bias_cls;
+}
 
 GSrc make_src(const float *p, int C, int layout, int H, int W, const void *p16 = nullptr)
 {
@@ -644,6 +659,9 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo) || !weight || !y) return DVSOF_EINVAL;
+    if (is_first_layer(d) && !residual)     // exact f32 in every operand mode
+        return first_fwd_launch(d->src[0].p, d->B, Ctot, d->H, d->W, weight, bias, d->act, y, z,
+                                d->mfma == 3 ? (unsigned short *)d->y16 : nullptr, as_stream(stream));
     GConvParams P = {};
     P.nsrc = d->nsrc;
     for (int i = 0; i < d->nsrc; ++i)
@@ -874,7 +892,12 @@ size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
     fill_wgrad(d, Ctot, Ho, Wo, P);
     FlatWG F[3];
     const int nflat = fill_flat(d, Ctot, Ho, Wo, nullptr, F);
-    return (wgrad_workspace_floats(P, true) + wgrad_flat_workspace_floats(F, nflat)) * sizeof(float) + 16;
+    size_t n = wgrad_workspace_floats(P, true) + wgrad_flat_workspace_floats(F, nflat);
+    if (is_first_layer(d)) {
+        const size_t nf = first_wgrad_workspace_floats(d->B, Ctot, d->H, d->W);
+        if (nf > n) n = nf;
+    }
+    return n * sizeof(float) + 16;
 }
 
 int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dweight, float *dbias,
@@ -918,6 +941,9 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
                                  gout, dweight, dbias, d->B, d->H, d->W, Ctot, d->Cout, mf, (float *)ws,
                                  ws_bytes / sizeof(float), as_stream(stream));
     }
+    if (is_first_layer(d) && !(d->flags & DVSOF_CONV_WGRAD_SKIP_FLAT))
+        return first_wgrad_launch(d->src[0].p, d->B, Ctot, d->H, d->W, gout, dweight, dbias, (float *)ws,
+                                  ws_bytes / sizeof(float), as_stream(stream));
     WGradParams P;
     fill_wgrad(d, Ctot, Ho, Wo, P);
     P.gout = gout;
@@ -1038,11 +1064,13 @@ int dvsof_conv2d_winograd_tile(const dvsof_conv_desc_t *d, int kind)
     return wino_tile(d->B, d->H, d->W, mfma);
 }
 
-// 2 when the LDS-DMA (v2) kernel serves this problem's vector members, else 1
+// 2 when the LDS-DMA (v2) kernel serves this problem's vector members, else 1;
+// 3: the first-layer kernels (first.hip); 0: flat members only on the VALU kernel
 int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *d, int kind)
 {
     int Ctot, Ho, Wo;
     if (!desc_ok(d, Ctot, Ho, Wo)) return DVSOF_EINVAL;
+    if (kind != 1 && is_first_layer(d)) return 3;
     if (kind == 2) {
         for (int i = 0; i < d->nsrc; ++i) {
             const GSrc g = make_src(d->src[i].p, d->src[i].C, d->src[i].layout, d->H, d->W);

@@ -642,6 +642,14 @@ int gconv2_launch(const GConvParams &P0, int tile, hipStream_t st)
         const long long blocks = ((P.M + 63) / 64) * ((P.N + 63) / 64) * P.nph;
         // ring depth 2 (64 KiB): a deeper ring is no faster stand-alone and its LDS
         // footprint keeps the second stream's workgroups off the CU
+        if (k64 && !no8 && P.mfma_bf16 == 3) {
+            // bf16 twins: 4 matrix instructions per wave and stage -- the loop is bound
+            // by the latency of the LDS-DMA stream, i.e. by the bytes in flight
+            // ((NS - 1) stages of 32 KiB), not by the matrix pipe as in f32
+            static const int ns3 = getenv("DVSOF_GCONV_K64_NS") ? atoi(getenv("DVSOF_GCONV_K64_NS")) : 4;
+            if (ns3 == 4) return launch2x<2, 2, 1, 1, 4, 4, 2, 3>(P, nflat, nvec, st);
+            if (ns3 == 3) return launch2x<2, 2, 1, 1, 4, 3, 2, 3>(P, nflat, nvec, st);
+        }
         if (k64 && !no8) return launch2<2, 2, 1, 1, 4, 2, 2>(P, nflat, nvec, st);
         if (k64) { /* 4-wave fallback keeps K32 counting */ return DVSOF_EINVAL; }
         // (<= 2 workgroups per CU: measured +3 % on the 512-workgroup decoder layers over the 4-wave form)

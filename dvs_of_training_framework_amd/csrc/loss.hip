@@ -12,7 +12,7 @@
 //      to zero) and workgroup 0 clears the group accumulators of launch B;
 //   B  loss_main_kernel: all scales, forward sums and flow gradients in one
 //      sweep;
-//   C  loss_reduce_kernel: one wave combines the per-group sums.
+//   C  loss_reduce_kernel: one workgroup (a wave per scale) combines the per-group sums.
 // Layout: flow [N,2,h,w] and frames [D,h,w] row-major.  A 256-thread
 // workgroup owns a 64x16 pixel tile of one sample at one scale: wave v owns
 // rows 4v..4v+3, lane l column l, so a thread holds a 4-pixel column strip.
@@ -119,56 +119,47 @@ __device__ __forceinline__ double group_value(const unsigned long long *p)
     return (double)(long long)*p * FIX_INV;
 }
 
-// Every group is complete.  One wave combines them: a group's 8 accumulators
-// are 64 contiguous bytes, so lane l reads element l % 8 of sample 8 j + l / 8
-// (8 samples per load instruction, the loads of ALL scales and of 2 sample
-// blocks in flight together: the chain of memory round trips is N / 16 long,
-// not N), lanes of equal l % 8 add their samples in j order, and the eight
-// lane groups meet by three shuffle steps.  Elements 0..4: sums over the
-// samples of photo + the four smoothness directions; element 5: border term
+// Every group is complete.  One workgroup combines them, wave v the scales v,
+// v + 4: a group's 8 accumulators are 64 contiguous bytes, so lane l reads
+// element l % 8 of sample 8 j + l / 8 -- 8 samples per load instruction, the
+// loads of 64 samples in flight together (ONE memory round trip per wave up to
+// batch 64; round 2's single wave walked the scales and 32-sample blocks in
+// turn: 9-14 us for 40 KB, a third of the whole path at batch 8) -- lanes of
+// equal l % 8 add their samples in j order and the eight lane groups meet by
+// three shuffle steps.  Elements 0..4: sums over the samples of photo + the
+// four smoothness directions (sums of exact multiples of 2^-20 in double:
+// exact, whatever the order); element 5: border term
 // = sum_n bs_n / (2 c_n N) with c_n = element 6 of the same sample
-// (utils/loss.py:101,113).
-__device__ __forceinline__ void final_terms(const Params &P)
+// (utils/loss.py:101,113), in the fixed order above.
+__device__ __forceinline__ void final_terms(const Params &P, double (*s_tot)[3])
 {
-    const int lane = threadIdx.x & (kWave - 1), e = lane & 7, g = lane >> 3;
-    double acc[DVSOF_MAX_SCALES];
-#pragma unroll
-    for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) acc[kk] = 0;
-    constexpr int UB = 4;       // sample blocks of 8 per pass: K * UB loads in flight per lane
-    for (int n0 = 0; n0 < P.N; n0 += 8 * UB) {
-        double x[DVSOF_MAX_SCALES][UB];
-#pragma unroll
-        for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk)
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, e = lane & 7, g = lane >> 3;
+    constexpr int UB = 8;       // sample blocks of 8 per pass: UB loads in flight per lane
+    for (int kk = wave; kk < P.K; kk += NW) {
+        double acc = 0;
+        for (int n0 = 0; n0 < P.N; n0 += 8 * UB) {
+            double x[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int nn = min(n0 + 8 * u + g, P.N - 1);
-                x[kk][u] = kk < P.K ? group_value(P.gacc + ((size_t)kk * P.N + nn) * NGROUP + e) : 0.0;
+                x[u] = group_value(P.gacc + ((size_t)kk * P.N + nn) * NGROUP + e);
             }
-#pragma unroll
-        for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) {
-            if (kk >= P.K) break;
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int nn = n0 + 8 * u + g;
-                const double c = __shfl(x[kk][u], (lane & ~7) | 6, kWave);    // the sample's count
+                const double c = __shfl(x[u], (lane & ~7) | 6, kWave);    // the sample's count
                 if (nn >= P.N) continue;
-                if (e < 5) acc[kk] += x[kk][u];
-                else if (e == 5 && c > 0) acc[kk] += x[kk][u] / (2.0 * c * (double)P.N);
+                if (e < 5) acc += x[u];
+                else if (e == 5 && c > 0) acc += x[u] / (2.0 * c * (double)P.N);
                 else if (e == 6) P.oob[kk * P.N + nn] = (int)c;    // kept for dvsof_loss_bwd
             }
         }
-    }
-    double total[3] = {0, 0, 0};
-#pragma unroll
-    for (int kk = 0; kk < DVSOF_MAX_SCALES; ++kk) {
-        if (kk >= P.K) break;
-        double a = acc[kk];
-        a += __shfl_xor(a, 8, kWave);
-        a += __shfl_xor(a, 16, kWave);
-        a += __shfl_xor(a, 32, kWave);
+        acc += __shfl_xor(acc, 8, kWave);
+        acc += __shfl_xor(acc, 16, kWave);
+        acc += __shfl_xor(acc, 32, kWave);
         double a6[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) a6[j] = __shfl(a, j, kWave);
+        for (int j = 0; j < 6; ++j) a6[j] = __shfl(acc, j, kWave);
         if (lane == 0) {
             const ScaleDev &S = P.s[kk];
             // empty crops contribute 0 (utils/loss.py:29-30)
@@ -180,14 +171,19 @@ __device__ __forceinline__ void final_terms(const Params &P)
             P.terms[0 * P.K + kk] = (float)sm;
             P.terms[1 * P.K + kk] = (float)ph;
             P.terms[2 * P.K + kk] = (float)border;
-            total[0] += sm;
-            total[1] += ph;
-            total[2] += border;
+            s_tot[kk][0] = sm;
+            s_tot[kk][1] = ph;
+            s_tot[kk][2] = border;
         }
     }
-    if (lane == 0 && P.loss_out)  // combined_loss, utils/training.py:23
+    __syncthreads();
+    if (threadIdx.x == 0 && P.loss_out) {   // combined_loss, utils/training.py:23
+        double total[3] = {0, 0, 0};
+        for (int kk = 0; kk < P.K; ++kk)
+            for (int i = 0; i < 3; ++i) total[i] += s_tot[kk][i];
         P.loss_out[0] = (float)((P.wts[0] * total[0] + P.wts[1] * total[1] + P.wts[2] * total[2]) /
                                 (double)P.K * (double)P.loss_scale);
+    }
 }
 
 template <bool FWD, bool BWD>
@@ -481,7 +477,11 @@ __global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
 // atomic round trip per workgroup, a CU cannot start the next workgroup while
 // its SIMD-0 slots are held by waves waiting for it, and the inlined
 // combination took the sweep from 96 to 160 VGPRs, 5 -> 3 waves per SIMD.)
-__global__ __launch_bounds__(kWave) void loss_reduce_kernel(const Params P) { final_terms(P); }
+__global__ __launch_bounds__(NT) void loss_reduce_kernel(const Params P)
+{
+    __shared__ double s_tot[DVSOF_MAX_SCALES][3];
+    final_terms(P, s_tot);
+}
 
 // Per-tile out-of-border pixel counts (utils/loss.py:101) ahead of the fused
 // forward+backward sweep: plain stores, one int per tile.  Workgroup 0 also
@@ -843,7 +843,7 @@ int dvsof_loss_fwd(const dvsof_loss_scale_t *sc, int K, int N, const int32_t *st
     DVSOF_LAUNCH_CHECK();
     hipLaunchKernelGGL((loss_main_kernel<true, false>), dim3(nb), dim3(NT), 0, as_stream(stream), P);
     DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, as_stream(stream), P);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(NT), 0, as_stream(stream), P);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
@@ -909,7 +909,7 @@ int fused_impl(const float *images, int D, int H, int W, const dvsof_loss_scale_
     }
     hipLaunchKernelGGL((loss_main_kernel<true, true>), dim3(nb), dim3(NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(kWave), 0, st, P);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(NT), 0, st, P);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

@@ -170,15 +170,21 @@ class _PredictorFn(torch.autograd.Function):
             if side is not None:
                 pre_ready = torch.cuda.Event()
                 pre_ready.record(side)
-        waited = [False]
+        waited, waited16 = [False], [False]
         # bf16-twins mode: the twins of the weights that are used as they are
         # (stride-2 encoder layers, direct residual layers) in ONE launch; the
         # twins of prepared forms come from the kernels that make the forms
-        raw16 = {}
+        raw16, raw16_ready = {}, None
         if twins:
             raws = [e_[0] for e_ in enc] + [r_[j] for r_ in res for j in (0, 2)]
-            raw16 = {id(w_): t_ for w_, t_ in
-                     zip(raws, C.to_bf16_many([_phys(w_) for w_ in raws]))}
+            # on the second stream when there is one (16 us off the forward's lane): the
+            # first layer does not read them, the main stream waits before the second
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                raw16 = {id(w_): t_ for w_, t_ in
+                         zip(raws, C.to_bf16_many([_phys(w_) for w_ in raws]))}
+                if side is not None:
+                    raw16_ready = torch.cuda.Event()
+                    raw16_ready.record(side)
 
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
@@ -231,6 +237,9 @@ class _PredictorFn(torch.autograd.Function):
                 w_fwd, w_dg, w_fwd16, w_dg16 = _prep(
                     d, _phys(wgt), need_dg, want16=twins)
             if twins and w_fwd16 is None:
+                if raw16_ready is not None and not waited16[0]:
+                    main.wait_event(raw16_ready)
+                    waited16[0] = True
                 w_fwd16 = raw16.get(id(wgt))
                 if w_fwd16 is None or w_fwd is not wgt:
                     w_fwd16 = C.to_bf16(w_fwd)
@@ -283,6 +292,7 @@ class _PredictorFn(torch.autograd.Function):
                 ctx.dg_ready = torch.cuda.Event()
                 ctx.dg_ready.record(side)
             ctx.L, ctx.act, ctx.dims = L, act, (B, Cin, H, W)
+            ctx.raw16 = raw16       # made on the second stream, read on this one: alive until backward
             ctx.params = params
             ctx.module = module
         return tuple(flows)

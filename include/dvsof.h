@@ -414,7 +414,10 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *desc, const float *gout,
  */
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *desc, int kind);
 /* kernel generation serving the problem: 2 = LDS-DMA ring (gconv2/wgrad2),
- * 1 = register-staged (gconv/wgrad), 0 = VALU-only (flat members). */
+ * 1 = register-staged (gconv/wgrad), 0 = VALU-only (flat members),
+ * 3 = the first encoder layer's own kernels (csrc/first.hip: one planar source
+ * of <= 16 channels, 3x3 stride 2 pad 1, 64 outputs, even frame sides; forward
+ * and weight gradient, exact f32 in every operand mode). */
 int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *desc, int kind);
 
 /* wt[ci][k*k-1-tap][co] = w[co][tap][ci] */

@@ -56,6 +56,15 @@ CASES = [
     dict(B=8, H=64, W=64, src=[(32, 'nhwc'), (32, 'nhwc'), (2, 'nchw')], Cout=64, up=True),
     # too few tiles: the direct kernel (transformed weights would dominate)
     dict(B=1, H=8, W=8, src=[(256, 'nhwc')], Cout=256, stride=1),
+    # the first encoder layer's own kernels (csrc/first.hip: planar input, 64 outputs,
+    # 8 x 32-pixel tiles, K = 9 C): ragged tiles in both directions, every column-block
+    # count of the weight gradient (K + 1 = 28 .. 145 columns), Mish with its z copy
+    dict(B=2, H=20, W=72, src=[(5, 'nchw')], Cout=64, stride=2, first=True),
+    dict(B=1, H=16, W=64, src=[(12, 'nchw')], Cout=64, stride=2, act='mish', first=True),
+    dict(B=3, H=34, W=18, src=[(9, 'nchw')], Cout=64, stride=2, first=True),
+    dict(B=1, H=8, W=8, src=[(16, 'nchw')], Cout=64, stride=2, first=True),
+    dict(B=1, H=8, W=8, src=[(3, 'nchw')], Cout=64, stride=2, first=True),
+    dict(B=8, H=128, W=128, src=[(5, 'nchw')], Cout=64, stride=2, first=True),   # 256 tiles: one per group
 ]
 
 
@@ -118,6 +127,8 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     res = torch.randn(case['B'], case['Cout'], ho, wo) if case.get('residual') else None
     y_ref, z_ref = torch_fwd(xs, w, b, o, act, C, res)
     import ctypes
+    first = C._lib.lib().dvsof_conv2d_kernel_generation(ctypes.byref(desc), 0) == 3
+    assert first == (bool(case.get('first')) or ci == 0)       # (case 0 has the first layer's shape too)
     nscratch = C._lib.lib().dvsof_conv2d_scratch_bytes(ctypes.byref(desc))
     # the Winograd path is the one under test (bf16-rounded operands stay direct)
     assert (nscratch > 0) == (bool(case.get('wino')) and mfma != 'bf16')
