@@ -74,6 +74,9 @@ struct GConvParams {
                         //    (gconv2 only; other kernels treat it as 1)
     int ph_exact;       // phased stride-2 dgrad: phase (py,px) only has (1+py) x (1+px) non-zero
                         // taps; a kernel MAY skip the others (they multiply zero weights)
+    int xcd;            // 1: workgroups are re-mapped so that an XCD (linear id % 8) owns a contiguous
+                        // range of (row tile, column tile, phase) with the phase fastest: the phases
+                        // and column tiles of one row tile share its input rows in ONE L2
     int dbg;            // DVSOF_GCONV_DBG (timing probes): 1 = skip the epilogue, 2 = one K step, 4 = loads from one L2-resident KiB,
                         // 8 = no DMA in the loop, 16 = no fragment reads, 32 = no barrier,
                         // 128 = every K step re-reads chunk 0 (cache-resident footprint)
@@ -98,6 +101,9 @@ struct WGradParams {
     long long src_ph_stride;   // elements between the source planes of two phases (winograd.hip)
     const unsigned short *gout16;   // bf16 twin of gout (mfma mode 3) or null
     int twins;            // 1: the vector members and gout are read from their bf16 twins (wgrad2_twins_kernel)
+    int xcd;              // 1: XCD-aware workgroup order (an XCD owns a contiguous range of tiles, column
+                          // tile fastest: the column tiles of a (row tile, K split) read the same
+                          // gradient slab through one L2)
 };
 
 // Weight gradient of one flat concat member on the VALU (wgrad.hip), in the

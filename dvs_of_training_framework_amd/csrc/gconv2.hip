@@ -82,7 +82,21 @@ __global__ __launch_bounds__(CONV_NT *KSPLIT) void gconv2_kernel(const GConvPara
     // gets whole components, so weight and row tiles are fetched into one L2 --
     // measured no change: 34.2 us either way; the probes below show the launch
     // is bound by its fixed costs and by 2.25 workgroups per CU, not by memory.)
-    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (P.xcd) {
+        // Workgroups are dispatched in linear-id order (x fastest), round-robin over the 8
+        // XCDs.  Each XCD has its own L2: give XCD i the i-th contiguous eighth of the tiles
+        // in (row tile, column tile, phase) order, phase fastest -- the 4 sub-pixel phases and
+        // the column tiles of a row tile read the same input rows, now through one L2 and
+        // close together in time (bf16 twins: the finest decoder stage fetched its 34 MB of
+        // inputs 6 times over, profiles/round3/b_traffic_pmc_bf16s.csv)
+        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned t = (L & 7u) * ((gx * gy * gz) >> 3) + (L >> 3);
+        bz = (int)(t % gz);
+        by = (int)((t / gz) % gy);
+        bx = (int)(t / (gz * gy));
+    }
     const int m0 = bx * BM, n0 = by * BN;
     const int taps = P.ks * P.ks;
     // exact-tap phases differ 4x in work: the heavy ones are dispatched first
@@ -545,8 +559,17 @@ int launch2x(const GConvParams &P, int nflat, int nvec, hipStream_t st)
         attr_set = true;
     }
     dim3 grid((P.M + BM - 1) / BM, (P.N + BN - 1) / BN, P.nph);
+    GConvParams Q = P;
+    {   // XCD-aware tile order (see the kernel): DVSOF_GCONV_XCD = 0 off (default: on)
+        static const int xe = getenv("DVSOF_GCONV_XCD") ? atoi(getenv("DVSOF_GCONV_XCD")) : -1;
+        const unsigned total = grid.x * grid.y * grid.z;
+        const bool want = xe != 0;
+        // (not the exact-tap phases: they differ 4x in work and are dispatched heavy first;
+        // phase-fastest order put heavy ones into the tail: stride-2 data gradients +20-40 %)
+        Q.xcd = (want && TAG == 0 && !P.ph_exact && (total & 7u) == 0 && total >= 64) ? 1 : 0;
+    }
     hipLaunchKernelGGL((gconv2_kernel<WROWS, WCOLS, TM, TN, KSUB, NS, KSPLIT, BF16, TAG>), grid,
-                       dim3(CONV_NT * KSPLIT), LDS, st, P, nflat, nvec);
+                       dim3(CONV_NT * KSPLIT), LDS, st, Q, nflat, nvec);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

@@ -41,7 +41,15 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_kernel(const WGradParams P)
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int taps = P.ks * P.ks;
 
-    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (P.xcd) {    // see gconv2.hip: linear id % 8 = XCD; each XCD gets a contiguous eighth of the tiles
+        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned t = (L & 7u) * ((gx * gy * gz) >> 3) + (L >> 3);
+        bx = (int)(t % gx);
+        by = (int)((t / gx) % gy);
+        bz = (int)(t / (gx * gy));
+    }
     int s = 0;
     for (int i = 1; i < P.nsrc; ++i)
         if (bx >= P.tile_begin[i]) s = i;
@@ -343,7 +351,15 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_twins_kernel(const WGradParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int taps = P.ks * P.ks;
-    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (P.xcd) {    // see gconv2.hip: linear id % 8 = XCD; each XCD gets a contiguous eighth of the tiles
+        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned t = (L & 7u) * ((gx * gy * gz) >> 3) + (L >> 3);
+        bx = (int)(t % gx);
+        by = (int)((t / gx) % gy);
+        bz = (int)(t / (gx * gy));
+    }
     int s = 0;
     for (int i = 1; i < P.nsrc; ++i)
         if (bx >= P.tile_begin[i]) s = i;
@@ -577,6 +593,17 @@ __global__ __launch_bounds__(CONV_NT) void wgrad2_twins_kernel(const WGradParams
 
 namespace {
 
+// XCD-aware tile order: DVSOF_WGRAD_XCD = 0 off (default: on; measured per launch at batch 8:
+// f32 -1..-3 %, bf16 operands up to -10 %, bf16 twins unchanged)
+inline int wgrad_xcd(dim3 grid, bool bf16)
+{
+    static const int xe = getenv("DVSOF_WGRAD_XCD") ? atoi(getenv("DVSOF_WGRAD_XCD")) : -1;
+    const unsigned total = grid.x * grid.y * grid.z;
+    const bool want = xe != 0;
+    (void)bf16;
+    return (want && (total & 7u) == 0 && total >= 64) ? 1 : 0;
+}
+
 template <int WROWS, int WCOLS, int TM, int TN, int BF16, int TAG = 0>
 int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
 {
@@ -590,7 +617,9 @@ int launch_w2x(const WGradParams &P, int ntiles, hipStream_t st)
         attr_set = true;
     }
     dim3 grid(ntiles, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
-    hipLaunchKernelGGL((wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16, TAG>), grid, dim3(CONV_NT), LDS, st, P);
+    WGradParams Q = P;
+    Q.xcd = wgrad_xcd(grid, P.mfma_bf16 != 0 || P.twins);
+    hipLaunchKernelGGL((wgrad2_kernel<WROWS, WCOLS, TM, TN, BF16, TAG>), grid, dim3(CONV_NT), LDS, st, Q);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
@@ -608,7 +637,9 @@ int launch_w2t(const WGradParams &P, int ntiles, hipStream_t st)
         attr_set = true;
     }
     dim3 grid(ntiles, (P.Cout + BMc - 1) / BMc, P.S * P.nph);
-    hipLaunchKernelGGL((wgrad2_twins_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), LDS, st, P);
+    WGradParams Q = P;
+    Q.xcd = wgrad_xcd(grid, P.mfma_bf16 != 0 || P.twins);
+    hipLaunchKernelGGL((wgrad2_twins_kernel<WROWS, WCOLS, TM, TN>), grid, dim3(CONV_NT), LDS, st, Q);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }

@@ -33,6 +33,19 @@ import torch
 from . import voxel
 
 WIRE_COLUMNS = ('x', 'y', 'timestamp', 'polarity', 'element_index', 'sample_index')
+_COPY_STREAMS = {}      # device index -> THE copy stream of that device
+
+
+def copy_stream(device):
+    """One copy stream per device for every feeder of the process: ROCclr binds
+    each new stream to one of GPU_MAX_HW_QUEUES hardware queues, and a stream
+    per feeder would sooner or later share a queue with the compute streams
+    (the copies would then wait behind kernels; see parallel.claim_streams)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _COPY_STREAMS[key]
 
 
 def _pow2_at_least(n, floor=4096):
@@ -62,7 +75,7 @@ class DeviceFeeder:
         self.slots = [_Slot(i) for i in range(slots)]
         self.event_capacity = event_capacity
         self.columns = columns
-        self.stream = copy_stream or torch.cuda.Stream(device=self.device)
+        self.stream = copy_stream or globals()['copy_stream'](self.device)
         self.bytes_moved = 0
         self.batches = 0
 

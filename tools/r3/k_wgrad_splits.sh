@@ -15,3 +15,5 @@ python3 tools/timeline.py $f 30 > $OUT/feed_timeline.txt 2>&1
 head -4 $OUT/feed_timeline.txt; grep copy $OUT/feed_timeline.txt | head -20
 grep "feeder\|samples_per_s" $OUT/feed.log | tail -3
 rm -rf $OUT/feed
+echo "== loss probes B=64 256x256 (probe build)"
+for d in 0 256 512 128 16; do echo -n "DBG=$d: "; DVSOF_LOSS_DBG=$d DVSOF_PROBE_LIB=1 python3 tools/loss_probe.py 64 256 256 2>/dev/null; done
