@@ -36,10 +36,19 @@ Rccl &rccl()
 {
     static Rccl r;
     if (r.handle || r.ok) return r;
+    // An RCCL that is ALREADY in the process first (RTLD_NOLOAD matches loaded objects by
+    // soname): a host that links its own copy -- PyTorch ships one -- then shares that one
+    // library with these entry points instead of mapping a second 570 MB librccl whose
+    // exported symbols collide with the first.  Only then the usual search.
+    const char *loaded[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : loaded) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (r.handle) break;
+    }
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char *n : names) {
-        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!r.handle) return r;
     r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.handle, "ncclGetUniqueId");

@@ -125,15 +125,23 @@ def add_train_arguments(parser):           # utils/options.py:204-302
                         action='store_true')
     # --- additions of this build
     parser.add_argument('--compute-dtype', dest='compute_dtype', default='f32',
-                        choices=['f32', 'bf16x3', 'bf16'],
+                        choices=['f32', 'bf16x3', 'bf16', 'bf16s'],
                         help='matrix-core operand type of the conv stack: exact f32, '
-                             'bf16 hi+lo split (three products, ~f32 accuracy) or bf16; '
-                             'storage and accumulation are f32 in every mode')
+                             'bf16 hi+lo split (three products, ~f32 accuracy), bf16 '
+                             '(operands rounded in registers; storage and accumulation '
+                             'f32) or bf16s (bf16 twins of activations / gradients / '
+                             'weight forms streamed through LDS; master weights, '
+                             'gradients of weights and optimizer state stay f32)')
     parser.add_argument('--capture', action='store_true',
-                        help='replay the loop body as one hipGraph launch per '
-                             'step once a batch signature has been seen '
-                             '(capture.CapturedTrainStep; ADAM, single process, '
-                             'no gradient accumulation)')
+                        help='replay the loop body from one C call per micro-batch '
+                             'once a batch signature has been seen (capture.CapturedLoop '
+                             '/ the step executor; ADAM; with or without gradient '
+                             'accumulation, with or without data parallelism -- the '
+                             'executor then issues the gradient exchange)')
+    parser.add_argument('--device-feeder', dest='device_feeder', action='store_true',
+                        help='move batches to the device on a copy stream, one step '
+                             'ahead (feed.DeviceFeeder), instead of tensor.to(device) '
+                             'at the top of every step (utils/training.py:45-56)')
     parser.add_argument('--compact-events', dest='compact_events',
                         action='store_true',
                         help='with --preprocessed-dataset-path: hand raw '

@@ -235,6 +235,25 @@ def test_train_loop_reduces_loss_and_accumulates():
     assert [x for t, v, x in Log.rows if t == 'General/Train loss'] == [4, 8, 12, 16, 20, 24]
 
 
+def test_cli_with_capture_accumulation_and_device_feeder(tmp_path):
+    """train_flownet.main end to end on synthetic batches: --capture with
+    bs // mbs = 2 micro-batches per optimizer step (the roles of capture.py),
+    batches moved by feed.DeviceFeeder; the checkpoint the reference's
+    serializer would load is written (utils/serializer.py:60-110 schema)."""
+    import train_flownet as tf
+    out = tmp_path / 'model'
+    pkg = Path(tf.__file__).resolve().parent / 'dvs_of_training_framework_amd'
+    tf.main(['-m', str(out), '--flownet_path', str(pkg), '--optimizer', 'ADAM', '-bs', '4', '-mbs', '2', '--height', '64',
+             '--width', '64', '-lr', '1e-3', '--event-representation-depth', '3', '--synthetic',
+             '--synthetic-events', '3000', '-ne', '5', '-d', 'cuda:0', '--capture',
+             '--device-feeder'])
+    ckpt = torch.load(out / 'step_5.pt', weights_only=True)
+    assert set(ckpt) >= {'model', 'optimizer', 'global_step'} and ckpt['global_step'] == 5
+    steps = {int(v['step']) for v in ckpt['optimizer']['state'].values()}
+    assert steps == {5}         # one AdamW update per optimizer step, replayed or not
+    assert all(torch.isfinite(v).all() for v in ckpt['model'].values())
+
+
 def test_optical_flow_wrapper(tmp_path):
     # DummyNet/of.py:53-74,120-125 contract: NHWC numpy out
     from dvs_of_training_framework_amd import OpticalFlow

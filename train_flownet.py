@@ -204,6 +204,9 @@ def main(argv=None):
                 'no dataset pipeline importable (the reference\'s utils.* and '
                 f'h5py are needed: {e}); pass --synthetic') from e
 
+    if getattr(args, 'device_feeder', False) and device.type == 'cuda' and args.is_raw:
+        from dvs_of_training_framework_amd.feed import DeviceFeeder
+        loader = DeviceFeeder(loader, device)
     train(model, device, loader, optimizer, args.training_steps,
           scheduler=scheduler, evaluator=losses, logger=logger,
           weights=args.loss_weights, is_raw=args.is_raw,
