@@ -687,6 +687,12 @@ def main():
         print(json.dumps(out), flush=True)
     barrier()
     if torch.distributed.is_initialized():
+        try:        # the C ABI's own communicator (made for the executor's exchange marks)
+            if 'h' in dir() and h.reducer is not None:
+                h.suspend_graph()
+                h.reducer.close()
+        except Exception as e:      # noqa: BLE001 -- shutting down
+            print(f'reducer.close: {e}', file=sys.stderr)
         torch.distributed.destroy_process_group()
 
 

@@ -213,6 +213,8 @@ def main(argv=None):
           accumulation_steps=args.accum_step, timers=timers, hooks={},
           max_events_per_batch=args.max_events_per_batch, reducer=reducer,
           capture=getattr(args, 'capture', False))
+    if reducer is not None:
+        reducer.close()
     if rank == 0:
         torch.save({'model': model.state_dict(),
                     'optimizer': optimizer.state_dict(),
