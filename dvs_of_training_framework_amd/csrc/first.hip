@@ -47,6 +47,7 @@ struct FirstP {
     float *part;               // weight gradient: [G][64][NCB*32] partial sums
     int B, C, H, W, Ho, Wo, K, KP, act;
     int tiles_x, tiles_y, ntiles;
+    int dbg;                   // DVSOF_FIRST_DBG (probe build): 1 no stores, 2 no matrix loop, 4 no patch load, 8 no weight load
 };
 
 // LDS image shared by both kernels: patch[C][F_PH][F_PW] + one zero + one 1.0f
@@ -55,18 +56,19 @@ __device__ __forceinline__ int patch_floats(int C) { return C * F_PH * F_PW + 2;
 // All loads of a batch first, then the LDS stores: a rolled load -> store loop
 // is one dependent memory round trip per element (22 per thread at C = 5: the
 // first version of this file spent 25 of its 37 us there).
-__device__ __forceinline__ void load_patch(const FirstP &P, float *patch, int b, int ty0, int tx0, int tid)
+__device__ __forceinline__ void load_patch(const FirstP &P, float *patch, int b, int ty0, int tx0, int tid,
+                                           int nthr = CONV_NT)
 {
     const int n = P.C * F_PH * 65;
     const float *xb = P.x + (size_t)b * P.C * P.H * P.W;
     const int gy0 = 2 * ty0 - 1, gx0 = 2 * tx0 - 1;
     constexpr int PBATCH = 24;
-    for (int e0 = 0; e0 < n; e0 += PBATCH * CONV_NT) {
+    for (int e0 = 0; e0 < n; e0 += PBATCH * nthr) {
         float v[PBATCH];
         int dst[PBATCH];
 #pragma unroll
         for (int j = 0; j < PBATCH; ++j) {
-            const int e = e0 + j * CONV_NT + tid;
+            const int e = e0 + j * nthr + tid;
             const int c = e / (F_PH * 65), r = e - c * (F_PH * 65);
             const int py = r / 65, px = r - py * 65;
             const int gy = gy0 + py, gx = gx0 + px;
@@ -105,26 +107,32 @@ __global__ __launch_bounds__(CONV_NT) void first_fwd_kernel(const FirstP P)
     const int b = bid / (P.tiles_x * P.tiles_y), t = bid - b * (P.tiles_x * P.tiles_y);
     const int ty0 = (t / P.tiles_x) * FT_H, tx0 = (t % P.tiles_x) * FT_W;
 
-    {   // wl[k][cout] = w[cout][k], loads in flight together (batches of 16)
-        const int nw = F_N * P.KP;
-        constexpr int WBATCH = 16;
-        for (int i0 = 0; i0 < nw; i0 += WBATCH * CONV_NT) {
-            float v[WBATCH];
-            int dst[WBATCH];
+    // Two independent fills, each a round trip to memory: half the workgroup stages the
+    // weights (wl[k][cout] = w[cout][k]), the other half the input patch -- one round trip
+    // instead of two in a row (probe build, batch 8: each costs ~5 us of the launch)
+    if (tid < CONV_NT / 2) {
+        if (!(DVSOF_DBG(P) & 8)) {
+            const int nw = F_N * P.KP, nthr = CONV_NT / 2;
+            constexpr int WBATCH = 24;
+            for (int i0 = 0; i0 < nw; i0 += WBATCH * nthr) {
+                float v[WBATCH];
+                int dst[WBATCH];
 #pragma unroll
-            for (int j = 0; j < WBATCH; ++j) {
-                const int i = i0 + j * CONV_NT + tid;
-                const int cout = i / P.KP, k = i - cout * P.KP;
-                dst[j] = i < nw ? k * F_N + cout : -1;
-                v[j] = (i < nw && k < P.K) ? P.w[(size_t)cout * P.K + k] : 0.f;
+                for (int j = 0; j < WBATCH; ++j) {
+                    const int i = i0 + j * nthr + tid;
+                    const int cout = i / P.KP, k = i - cout * P.KP;
+                    dst[j] = i < nw ? k * F_N + cout : -1;
+                    v[j] = (i < nw && k < P.K) ? P.w[(size_t)cout * P.K + k] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < WBATCH; ++j)
+                    if (dst[j] >= 0) wl[dst[j]] = v[j];
             }
-#pragma unroll
-            for (int j = 0; j < WBATCH; ++j)
-                if (dst[j] >= 0) wl[dst[j]] = v[j];
         }
+        for (int k = tid; k < P.KP; k += CONV_NT / 2) koff[k] = k_offset(P, k);
+    } else if (!(DVSOF_DBG(P) & 4)) {
+        load_patch(P, patch, b, ty0, tx0, tid - CONV_NT / 2, CONV_NT / 2);
     }
-    for (int k = tid; k < P.KP; k += CONV_NT) koff[k] = k_offset(P, k);
-    load_patch(P, patch, b, ty0, tx0, tid);
     __syncthreads();
 
     const int cx = lane & 31, half = lane >> 5;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(CONV_NT) void first_fwd_kernel(const FirstP P)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 #pragma unroll 4
-    for (int k0 = 0; k0 < P.KP; k0 += 2) {
+    for (int k0 = 0; k0 < ((DVSOF_DBG(P) & 2) ? 2 : P.KP); k0 += 2) {
         const int k = k0 + half;
         const int off = koff[k];
         const float b0 = wl[k * F_N + cx], b1 = wl[k * F_N + 32 + cx];
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(CONV_NT) void first_fwd_kernel(const FirstP P)
     for (int it = 0; it < RPW * 8; ++it) {
         const int px = 4 * it + pl, mb = px >> 5;
         const int oy = ty0 + RPW * wave + mb, ox = tx0 + (px & 31);
-        if (oy >= P.Ho || ox >= P.Wo) continue;
+        if (oy >= P.Ho || ox >= P.Wo || ((DVSOF_DBG(P) & 1) && px > 0)) continue;
         const f32x4 v = *(const f32x4 *)(stage + px * F_N + c4);
         const size_t o = (((size_t)b * P.Ho + oy) * P.Wo + ox) * F_N + c4;
         if (P.z) *(f32x4 *)(P.z + o) = v;
@@ -368,6 +376,9 @@ int first_fwd_launch(const float *x, int B, int C, int H, int W, const float *w,
     P.z = z;
     P.y16 = y16;
     P.act = act;
+#ifdef DVSOF_PROBES
+    P.dbg = getenv("DVSOF_FIRST_DBG") ? atoi(getenv("DVSOF_FIRST_DBG")) : 0;
+#endif
     size_t lds = ((size_t)C * F_PH * F_PW + 2 + (size_t)P.KP * F_N + P.KP) * 4;
     if (lds < (size_t)4 * RPW * 32 * F_N * 4) lds = (size_t)4 * RPW * 32 * F_N * 4;     // the epilogue's staging area
     static size_t lds_set = 0;
