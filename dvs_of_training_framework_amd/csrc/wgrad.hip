@@ -890,11 +890,21 @@ int pick_tile_and_splits(const WGradParams &P, int *S_out)
 
 }  // namespace
 
+// wgrad_patch.hip: the decoder stages in the bf16-twins mode, input patch resident in LDS
+bool wgrad_patch_shape_ok(const WGradParams &P);
+bool wgrad_patch_eligible(const WGradParams &P);
+int wgrad_patch_splits(const WGradParams &P);
+int wgrad_patch_launch(const WGradParams &P, hipStream_t st);
+
 // Number of K splits used for this problem (deterministic in the shape).
 int wgrad_splits(const WGradParams &P0, int *tile_out)
 {
     int S = 1;
     int tile = pick_tile_and_splits(P0, &S);
+    if (wgrad_patch_eligible(P0)) {     // its own split rule (workgroups are K splits there)
+        if (tile_out) *tile_out = tile;
+        return wgrad_patch_splits(P0);
+    }
     // tuning sweeps (tools/wgrad_sweep.sh): force the tile and / or the K splits
     static const int tile_env = getenv("DVSOF_WGRAD_TILE") ? atoi(getenv("DVSOF_WGRAD_TILE")) : 0;
     static const int s_env = getenv("DVSOF_WGRAD_SPLITS") ? atoi(getenv("DVSOF_WGRAD_SPLITS")) : 0;
@@ -947,7 +957,8 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
                 P.dbias = direct ? dbias : bias_part;
                 bias_in_kernel = true;
             }
-            rc = wgrad2_launch(P, tile, nt, st);
+            rc = (!direct && wgrad_patch_eligible(P)) ? wgrad_patch_launch(P, st)
+                                                      : wgrad2_launch(P, tile, nt, st);
             P.dbias = nullptr;
         }
         if (rc) return rc;
@@ -1031,7 +1042,10 @@ size_t wgrad_flat_workspace_floats(const FlatWG *flat, int nflat)
 
 size_t wgrad_workspace_floats(const WGradParams &P, bool with_bias)
 {
-    const int nslab = wgrad_splits(P, nullptr) * P.nph;
+    int S = wgrad_splits(P, nullptr);
+    // the twins may not be bound yet when the workspace is sized: room for either kernel
+    if (wgrad_patch_shape_ok(P) && wgrad_patch_splits(P) > S) S = wgrad_patch_splits(P);
+    const int nslab = S * P.nph;
     return (nslab <= 1 ? 0 : (size_t)nslab * P.Cout * P.ks * P.ks * P.Cin_tot) +
            (with_bias ? (size_t)COLSUM_MAX_BLOCKS * P.Cout : 0);
 }

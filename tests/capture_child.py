@@ -298,6 +298,8 @@ def scenario_big(dtype):
         return [float(v) for v in losses], weights
     l_e, w_e = eager()
     l_r, w_r = replayed()
+    if red is not None:
+        red.close()
     return {'losses_equal': l_e == l_r, 'weights_equal': all(torch.equal(a, b) for a, b in zip(w_e, w_r)),
             'eager': l_e, 'replayed': l_r, 'executor': info, 'dist': red is not None,
             'max_weight_diff': max(float((a - b).abs().max()) for a, b in zip(w_e, w_r))}
@@ -385,7 +387,10 @@ def scenario_accum(dp=False):
     red = _dist() if dp else None
     data = [unique_pixel_batch(300 + i, B, H, W, 4096 if i % 4 else 3100) for i in range(12)]
     data[7] = unique_pixel_batch(307, 1, H, W, 4000)     # another signature, as a 'middle'
-    return _compare(data, accum=3, red=red)
+    out = _compare(data, accum=3, red=red)
+    if red is not None:
+        red.close()
+    return out
 
 
 def scenario_compact():
@@ -446,6 +451,16 @@ def scenario_audit():
             'bad_unheld': len(bad['unheld'])}
 
 
+def _shutdown():
+    """Orderly end of a 1-rank group: the C ABI's communicator, then the process group (an
+    exit with live communicators races RCCL's threads against the interpreter's teardown:
+    seen once as an abort after the result line had been printed)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
 if __name__ == '__main__':
     name, _, arg = sys.argv[1].partition(':')
     out = {'train': scenario_train, 'train_graph': lambda: scenario_train(False),
@@ -454,3 +469,4 @@ if __name__ == '__main__':
            'compact': scenario_compact, 'grow': scenario_grow, 'feed': lambda: scenario_feed(int(arg or 1)), 'fail': scenario_fail,
            'audit': scenario_audit}[name]()
     print(json.dumps(out), flush=True)
+    _shutdown()

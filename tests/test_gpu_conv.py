@@ -168,6 +168,12 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     dict(B=2, H=16, W=16, src=[(64, 'nhwc'), (32, 'nhwc'), (2, 'nchw')], Cout=32, up=True),   # sub-pixel phases + a flat member
     dict(B=8, H=64, W=64, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),                # 32 x 128 tile, many K splits
     dict(B=4, H=16, W=16, src=[(256, 'nhwc')], Cout=256, stride=1),                          # direct wide layer (no Winograd in mode 3)
+    # the patch-resident decoder kernel (csrc/wgrad_patch.hip; the 64 x 64 case above too):
+    # 16-pixel rows (every group is its own row: top / bottom / left / right borders in one
+    # group), two output-channel tiles, unequal members, an odd number of groups per split
+    dict(B=3, H=16, W=16, src=[(64, 'nhwc'), (32, 'nhwc')], Cout=64, up=True),
+    dict(B=2, H=8, W=32, src=[(32, 'nhwc')], Cout=32, up=True),
+    dict(B=1, H=16, W=48, src=[(96, 'nhwc'), (32, 'nhwc')], Cout=96, up=True),
 ])
 def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
     """mfma mode 3: the vector members' weight gradient streams the bf16 TWINS
