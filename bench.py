@@ -168,6 +168,19 @@ class Harness:
         self.sched.step()
         return loss
 
+    def settle(self, limit=40):
+        """Setup, not warm-up: step until every resident batch has its captured
+        step and every executor has chosen its lane plan (capture, calibration
+        and 6 timed trial steps per executor)."""
+        for _ in range(limit):
+            ex = [c.executor for c in self.captured_all.values()]
+            if getattr(self, 'launch_fallback', None) or not (
+                    getattr(self.a, 'executor', False) or getattr(self.a, 'graph', False)):
+                return
+            if len(ex) == len(self.batches) and all(e is None or e.plan()[1] for e in ex):
+                return
+            self.step()
+
     def suspend_graph(self):
         """Per-launch instrumentation needs eager launches."""
         for c in self.captured_all.values():
@@ -597,6 +610,7 @@ def main():
     # part of the W warm-up steps the caller asked for
     for _ in range(4):
         h.step()
+    h.settle()
     for _ in range(a.warmup):
         h.step()
     barrier()
@@ -642,6 +656,7 @@ def main():
         out['config']['launch'] = 'one hipGraph replay per step' if ex is None else (
             f'step executor: {ex.kernels} kernels on {ex.lanes} streams {ex.lane_kernels}, '
             f'{ex.events} events / {ex.waits} waits per step, one C call'
+            + f', lane plan "{ex.plan()[0]}"'
             + (f'; {ex.marks} exchange marks (bucket all-reduces issued by the executor on the '
                'exchange stream)' if ex.marks else ''))
     if not a.no_roofline:
@@ -662,6 +677,7 @@ def main():
             h2 = Harness(a2, rank, device)
             for _ in range(7):
                 h2.step()
+            h2.settle()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(20):

@@ -48,6 +48,7 @@ _SIGNATURES = {
     'dvsof_exec_calibrate': (_i, [_vp, _vp]),
     'dvsof_exec_node': (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_f),
                              ctypes.POINTER(_i), ctypes.c_char_p, _i]),
+    'dvsof_exec_plan': (_i, [_vp, ctypes.c_char_p, _i, ctypes.POINTER(_i)]),
     'dvsof_exec_destroy': (_i, [_vp]),
     'dvsof_exec_mark': (_i, [_i, _i, _vp, _sz, _vp]),
     'dvsof_exec_set_comm': (_i, [_vp, _vp, _vp]),

@@ -142,6 +142,14 @@ class StepExecutor:
         if rc:
             _lib.check(rc, 'dvsof_exec_launch')
 
+    def plan(self):
+        """(name of the lane plan in effect, settled?): after calibration the
+        executor tries its plans on the next steps and keeps the fastest."""
+        buf, settled = ctypes.create_string_buffer(32), ctypes.c_int()
+        _lib.check(_lib.lib().dvsof_exec_plan(self._handle, buf, 32, ctypes.byref(settled)),
+                   'dvsof_exec_plan')
+        return buf.value.decode(), bool(settled.value)
+
     def nodes(self):
         """[(lane, measured us, cross-lane waits, kernel name)] in launch order."""
         out, lane, us, nw = [], ctypes.c_int(), ctypes.c_float(), ctypes.c_int()

@@ -40,6 +40,7 @@
 // communicator (dvsof_exec_set_comm not called: one GPU) marks are skipped.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 #include <unordered_map>
 #include <vector>
@@ -60,14 +61,29 @@ struct XNode {
     size_t mark_n = 0;
     hipEvent_t mark_ev = nullptr;   // BUCKET: the lane's progress the exchange stream waits for
     int lane;
+    int id = 0;              // position in capture (topological) order: what plans are written in
+    int lane0 = 0;           // lane of the greedy chain split made at creation
     float us = 1.f;          // measured duration (dvsof_exec_calibrate)
-    std::vector<int> deps;   // positions of the nodes this one depends on
+    std::vector<int> deps_id;    // ids of the nodes this one depends on
+    std::vector<int> deps;   // their positions in the current launch order
     std::vector<int> wait;   // nodes of other lanes to wait for before the launch
     hipEvent_t ev;           // recorded after the launch when another lane waits for it
 };
 
+// A lane plan: launch order (node ids) and lane by node id.
+struct Plan {
+    const char *name;
+    std::vector<int> order, lane;
+    float best_us = 3.0e38f;     // fastest measured step under this plan
+};
+
 struct Exec {
-    std::vector<XNode> nodes;
+    std::vector<XNode> nodes;    // in launch order
+    std::vector<Plan> cands;     // plans being tried on the steps after calibration
+    int trial_next = -1;         // next trial (round-robin over cands), -1: settled
+    int trial_cur = -1;          // plan of the step in flight whose time is still to be read
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    const char *plan_name = "chain";
     std::vector<hipStream_t> side;   // lanes 1.. (lane 0 is the stream of the launch call)
     std::vector<int> tail;           // last node of every lane
     hipEvent_t fork = nullptr;
@@ -126,17 +142,19 @@ int wire(Exec *x)
     return DVSOF_OK;
 }
 
-// Lanes by measured time: lane l = the longest path (sum of node durations)
-// through the nodes no earlier lane took; the last lane takes the rest.
-void plan_by_time(Exec *x)
+// Plan 1, lanes by measured time: lane l = the longest path (sum of node
+// durations) through the nodes no earlier lane took; the last lane takes the
+// rest.  Launch order = capture order.
+Plan plan_by_time(const Exec *x)
 {
     const int nn = (int)x->nodes.size();
     std::vector<char> taken(nn, 0);
+    std::vector<int> lane(nn, 0);
     int left = nn;
-    for (int lane = 0; lane < x->max_lanes && left > 0; ++lane) {
-        if (lane == x->max_lanes - 1) {
+    for (int l = 0; l < x->max_lanes && left > 0; ++l) {
+        if (l == x->max_lanes - 1) {
             for (int i = 0; i < nn; ++i)
-                if (!taken[i]) x->nodes[i].lane = lane;
+                if (!taken[i]) lane[i] = l;
             break;
         }
         std::vector<double> best(nn, 0.0);
@@ -154,11 +172,129 @@ void plan_by_time(Exec *x)
             if (end < 0 || best[i] > best[end]) end = i;
         }
         for (int i = end; i >= 0; i = from[i]) {
-            x->nodes[i].lane = lane;
+            lane[i] = l;
             taken[i] = 1;
             --left;
         }
     }
+    Plan p;
+    p.name = "paths";
+    p.order.resize(nn);
+    p.lane.resize(nn);
+    std::vector<int> by_id(nn);
+    for (int i = 0; i < nn; ++i) by_id[x->nodes[i].id] = i;
+    for (int id = 0; id < nn; ++id) {
+        p.order[id] = id;
+        p.lane[id] = lane[by_id[id]];
+    }
+    return p;
+}
+
+// Plan 0: the greedy chain split of dvsof_exec_create, capture order.
+Plan plan_chain(const Exec *x)
+{
+    const int nn = (int)x->nodes.size();
+    Plan p;
+    p.name = "chain";
+    p.order.resize(nn);
+    p.lane.resize(nn);
+    for (const auto &n : x->nodes) {
+        p.order[n.id] = n.id;
+        p.lane[n.id] = n.lane0;
+    }
+    return p;
+}
+
+// Plan 2, list scheduling on the measured durations: lanes are in-order
+// queues; of the nodes whose dependencies are placed the one with the longest
+// remaining path to the end of the step goes next, onto the lane where it can
+// start first (a dependency in another lane costs `hop` us on top of its end).
+// The chain that bounds the step keeps flowing on one lane; whatever hangs off
+// it (weight gradients, folds, prepared forms) fills the other.  Also fixes
+// the LAUNCH order: the order nodes were placed in.
+Plan plan_by_list(const Exec *x, double hop)
+{
+    const int nn = (int)x->nodes.size(), L = x->max_lanes;
+    std::vector<std::vector<int>> succ(nn);
+    std::vector<int> indeg(nn, 0);
+    for (int i = 0; i < nn; ++i) {
+        indeg[i] = (int)x->nodes[i].deps.size();
+        for (int d : x->nodes[i].deps) succ[d].push_back(i);
+    }
+    {   // marks keep their capture order: every rank issues the same collectives in the
+        // same order whatever its own measured durations say
+        std::vector<int> marks;
+        for (int i = 0; i < nn; ++i)
+            if (x->nodes[i].mark) marks.push_back(i);
+        std::sort(marks.begin(), marks.end(), [&](int a, int b) { return x->nodes[a].id < x->nodes[b].id; });
+        for (size_t k = 1; k < marks.size(); ++k) {
+            succ[marks[k - 1]].push_back(marks[k]);
+            ++indeg[marks[k]];
+        }
+    }
+    std::vector<double> bl(nn, 0.0);
+    for (int i = nn - 1; i >= 0; --i) {     // positions are a topological order
+        double b = 0.0;
+        for (int s_ : succ[i]) b = std::max(b, bl[s_]);
+        bl[i] = b + (double)x->nodes[i].us;
+    }
+    std::vector<double> fin(nn, 0.0), free_at(L, 0.0);
+    std::vector<int> lane(nn, 0), ready;
+    for (int i = 0; i < nn; ++i)
+        if (!indeg[i]) ready.push_back(i);
+    Plan p;
+    p.name = "list";
+    p.order.reserve(nn);
+    p.lane.assign(nn, 0);
+    while (!ready.empty()) {
+        size_t pick = 0;
+        for (size_t k = 1; k < ready.size(); ++k) {
+            const int a = ready[k], b = ready[pick];
+            if (bl[a] > bl[b] || (bl[a] == bl[b] && a < b)) pick = k;
+        }
+        const int i = ready[pick];
+        ready.erase(ready.begin() + (long)pick);
+        int best_l = 0;
+        double best_t = 0.0;
+        for (int l = 0; l < L; ++l) {
+            double t = free_at[l];
+            for (int d : x->nodes[i].deps) t = std::max(t, fin[d] + (lane[d] != l ? hop : 0.0));
+            if (l == 0 || t < best_t) {
+                best_t = t;
+                best_l = l;
+            }
+        }
+        lane[i] = best_l;
+        fin[i] = best_t + (double)x->nodes[i].us;
+        free_at[best_l] = fin[i];
+        p.order.push_back(x->nodes[i].id);
+        p.lane[x->nodes[i].id] = best_l;
+        for (int s_ : succ[i])
+            if (--indeg[s_] == 0) ready.push_back(s_);
+    }
+    return p;
+}
+
+// Put the nodes in the plan's launch order and lanes; dependencies as positions again.
+void apply(Exec *x, const Plan &p)
+{
+    const int nn = (int)x->nodes.size();
+    std::vector<int> by_id(nn), newpos(nn);
+    for (int i = 0; i < nn; ++i) by_id[x->nodes[i].id] = i;
+    std::vector<XNode> nv;
+    nv.reserve(nn);
+    for (int k = 0; k < nn; ++k) {
+        newpos[p.order[k]] = k;
+        nv.push_back(std::move(x->nodes[by_id[p.order[k]]]));
+    }
+    for (auto &n : nv) {
+        n.lane = p.lane[n.id];
+        n.deps.clear();
+        for (int d : n.deps_id) n.deps.push_back(newpos[d]);
+        std::sort(n.deps.begin(), n.deps.end());
+    }
+    x->nodes.swap(nv);
+    x->plan_name = p.name;
 }
 
 void destroy(Exec *x)
@@ -168,6 +304,8 @@ void destroy(Exec *x)
         if (n.mark_ev) (void)hipEventDestroy(n.mark_ev);
     }
     if (x->xdone) (void)hipEventDestroy(x->xdone);
+    if (x->t0) (void)hipEventDestroy(x->t0);
+    if (x->t1) (void)hipEventDestroy(x->t1);
     if (x->fork) (void)hipEventDestroy(x->fork);
     for (auto e : x->join)
         if (e) (void)hipEventDestroy(e);
@@ -358,9 +496,10 @@ int dvsof_exec_create(void *graph_, void *const *side_streams, int n_side, void 
                 lane = max_lanes - 1;
             }
         }
-        n.lane = lane;
+        n.lane = n.lane0 = lane;
+        n.id = (int)i;
         tail[lane] = (int)i;
-        n.deps = deps;
+        n.deps = n.deps_id = deps;
     }
     for (int l = 0; l < n_side; ++l) x->side.push_back((hipStream_t)side_streams[l]);
     {
@@ -447,7 +586,54 @@ int dvsof_exec_calibrate(void *exec, void *stream)
     for (auto e : ev)
         if (e) (void)hipEventDestroy(e);
     if (rc) return rc;
-    plan_by_time(x);
+    // DVSOF_EXEC_PLAN = paths | list | chain: that plan; default: every plan is tried on
+    // the next steps (real steps, timed on the device), the fastest stays
+    static const char *want = getenv("DVSOF_EXEC_PLAN");
+    static const double hop = getenv("DVSOF_EXEC_HOP") ? atof(getenv("DVSOF_EXEC_HOP")) : 8.0;
+    x->cands.clear();
+    x->trial_next = x->trial_cur = -1;
+    if (x->max_lanes < 2) return wire(x);
+    x->cands.push_back(plan_by_time(x));
+    x->cands.push_back(plan_by_list(x, hop));
+    x->cands.push_back(plan_chain(x));
+    int fixed = -1;
+    for (size_t i = 0; want && i < x->cands.size(); ++i)
+        if (!strcmp(want, x->cands[i].name)) fixed = (int)i;
+    if (fixed >= 0) {
+        apply(x, x->cands[fixed]);
+        x->cands.clear();
+        return wire(x);
+    }
+    if (!x->t0) DVSOF_HIP_TRY(hipEventCreate(&x->t0));
+    if (!x->t1) DVSOF_HIP_TRY(hipEventCreate(&x->t1));
+    x->trial_next = 0;
+    apply(x, x->cands[0]);
+    return wire(x);
+}
+
+// Steps after calibration: plan k % n on trial k, `rounds` rounds; then the fastest.
+static int next_trial(Exec *x)
+{
+    static const int rounds = getenv("DVSOF_EXEC_TRIALS") ? std::max(1, atoi(getenv("DVSOF_EXEC_TRIALS"))) : 2;
+    const int n = (int)x->cands.size();
+    if (x->trial_cur >= 0) {    // the step in flight was a trial: its device time
+        DVSOF_HIP_TRY(hipEventSynchronize(x->t1));
+        float ms = 0.f;
+        DVSOF_HIP_TRY(hipEventElapsedTime(&ms, x->t0, x->t1));
+        Plan &p = x->cands[x->trial_cur];
+        p.best_us = std::min(p.best_us, ms * 1e3f);
+        x->trial_cur = -1;
+    }
+    if (x->trial_next < n * rounds) {
+        x->trial_cur = x->trial_next++ % n;
+        apply(x, x->cands[x->trial_cur]);
+        return wire(x);
+    }
+    int best = 0;
+    for (int i = 1; i < n; ++i)
+        if (x->cands[i].best_us < x->cands[best].best_us) best = i;
+    apply(x, x->cands[best]);
+    x->trial_next = -1;
     return wire(x);
 }
 
@@ -456,8 +642,13 @@ int dvsof_exec_launch(void *exec, void *stream)
     if (!exec) return DVSOF_EINVAL;
     Exec *x = (Exec *)exec;
     hipStream_t main = as_stream(stream);
+    if (x->trial_next >= 0) {
+        const int rc_ = next_trial(x);
+        if (rc_) return rc_;
+    }
     const int L = (int)x->tail.size();
     auto lane_stream = [&](int l) { return l == 0 ? main : x->side[l - 1]; };
+    if (x->trial_cur >= 0) DVSOF_HIP_TRY(hipEventRecord(x->t0, main));
     if (L > 1) {   // the side lanes start behind whatever precedes the step on `stream`
         DVSOF_HIP_TRY(hipEventRecord(x->fork, main));
         for (int l = 1; l < L; ++l) DVSOF_HIP_TRY(hipStreamWaitEvent(x->side[l - 1], x->fork, 0));
@@ -477,6 +668,20 @@ int dvsof_exec_launch(void *exec, void *stream)
     for (int l = 1; l < L; ++l) {   // `stream` continues behind every lane
         DVSOF_HIP_TRY(hipEventRecord(x->join[l - 1], x->side[l - 1]));
         DVSOF_HIP_TRY(hipStreamWaitEvent(main, x->join[l - 1], 0));
+    }
+    if (x->trial_cur >= 0) DVSOF_HIP_TRY(hipEventRecord(x->t1, main));
+    return DVSOF_OK;
+}
+
+int dvsof_exec_plan(void *exec, char *name, int name_len, int *settled)
+{
+    if (!exec) return DVSOF_EINVAL;
+    Exec *x = (Exec *)exec;
+    if (settled) *settled = x->trial_next < 0;
+    if (name && name_len > 0) {
+        int k = 0;
+        for (; k < name_len - 1 && x->plan_name[k]; ++k) name[k] = x->plan_name[k];
+        name[k] = 0;
     }
     return DVSOF_OK;
 }

@@ -89,6 +89,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(const uint64_t *__restrict__
     }
 }
 
+// The per-step table of a captured step ({lr, lr/bc1, sqrt(bc2)} per group) written from
+// KERNEL ARGUMENTS: a 16-byte host-to-device copy is a blit kernel with system-scope fences
+// (4 us + an 11 us bubble in front of the next kernel, at the head of every step)
+constexpr int DYN_VALUES = 64;
+struct DynValues {
+    float v[DYN_VALUES];
+};
+__global__ void set_dynamic_kernel(float *dyn, DynValues vals, int n)
+{
+    if ((int)threadIdx.x < n) dyn[threadIdx.x] = vals.v[threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" {
@@ -127,6 +139,19 @@ void dvsof_adamw_dynamic(float lr, float beta1, float beta2, int step, float *ho
     host_out3[0] = lr;
     host_out3[1] = (float)((double)lr / bc1);
     host_out3[2] = (float)sqrt(bc2);
+}
+
+int dvsof_adamw_set_dynamic(float *dyn, const float *host_values, int n, void *stream)
+{
+    if (!dyn || !host_values || n < 0) return DVSOF_EINVAL;
+    for (int o = 0; o < n; o += DYN_VALUES) {   // the values travel as kernel arguments
+        DynValues v;
+        const int m = n - o < DYN_VALUES ? n - o : DYN_VALUES;
+        for (int i = 0; i < DYN_VALUES; ++i) v.v[i] = i < m ? host_values[o + i] : 0.f;
+        hipLaunchKernelGGL(set_dynamic_kernel, dim3(1), dim3(DYN_VALUES), 0, as_stream(stream), dyn + o, v, m);
+        DVSOF_LAUNCH_CHECK();
+    }
+    return DVSOF_OK;
 }
 
 int dvsof_adamw_step_dyn(const uint64_t *ptrs, const int64_t *sizes, const int32_t *chunks,

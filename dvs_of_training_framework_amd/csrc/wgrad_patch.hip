@@ -34,19 +34,39 @@
 
 namespace {
 
-constexpr int WP_NS = 4;            // ring stages
-constexpr int WP_PG = 2;            // 16-pixel groups per stage
-constexpr int WP_XSLOT = 3 * 18;    // patch pixels per group
-constexpr int WP_XP = 7;            // pieces of the two patches (108 of 112 slots used)
-constexpr int WP_GP = 8;            // pieces of the gradient planes: 2 groups x 4 phases x 16 px
-constexpr int WP_PIECES = 16;       // + 1 dummy so that every wave issues 4 loads per stage
-constexpr int WP_LPW = WP_PIECES / 4;
-constexpr int WP_STAGE = WP_PIECES * 1024;
-constexpr unsigned WP_OOB = 0x80000000u;
+__attribute__((unused)) constexpr unsigned WP_OOB = 0x80000000u;
+constexpr int WP_XSLOT = 4 * 18;    // patch pixels of a block: rows i-1 .. i+2, columns j0-1 .. j0+16
 
+// CT input channels per workgroup (32 | 64): a pixel slot of the patch is 2 CT bytes.
+template <int CT>
+struct WPGeom {
+    static constexpr int PXB = 2 * CT;                  // bytes per patch pixel slot
+    static constexpr int LPS = PXB / 16;                // lanes (16-byte chunks) per slot
+    static constexpr int SPP = 64 / LPS;                // slots per 1 KiB piece
+    static constexpr int XP = (WP_XSLOT + SPP - 1) / SPP;   // pieces of the patch
+    static constexpr int GP = 8;                        // gradient planes: 4 phases x 32 px x 64 B
+    static constexpr int PIECES = (XP + GP + 3) / 4 * 4;    // every wave issues the same number of loads
+    static constexpr int LPW = PIECES / 4;
+    static constexpr int STAGE = PIECES * 1024;
+    static constexpr int NS = CT == 32 ? 4 : 3;         // ring stages (64 | 60 KiB: two workgroups per CU)
+    static constexpr int NB = CT / 32;                  // 32-column blocks per tap
+};
+
+// 128-byte pixel rows: the four pixel rows of a transposed fragment read are one pitch
+// apart and rows q, q + 2 would share banks -- the 64-byte half h of slot n holds channel
+// half h ^ ((n >> 1) & 1) (the lane FETCHES the permuted half; LDS-DMA destinations are
+// lane-linear and cannot be padded); 64-byte rows need nothing
+template <int CT>
+__device__ __forceinline__ int wp_swz(int n)
+{
+    return CT == 64 ? (n >> 1) & 1 : 0;
+}
+
+template <int CT>
 __global__ __launch_bounds__(CONV_NT) void wgrad_patch_twins_kernel(const WGradParams P)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    typedef WPGeom<CT> G;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -54,45 +74,61 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_patch_twins_kernel(const WGradP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pa = wave >> 1, pb = wave & 1;            // this wave's output phase
 
-    const int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, split = blockIdx.z;
+    if (P.xcd) {
+        // linear id % 8 = XCD: every XCD takes a contiguous range of (split, tile) pairs, tiles
+        // fastest -- the tiles of a split read the SAME gradient planes and the two 64-byte
+        // halves of the same 128-byte input lines, and now meet in one L2 (any grid size)
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned x = L & 7u, q = total >> 3, r = total & 7u;
+        const unsigned t = x * q + min(x, r) + (L >> 3);
+        bx = (int)(t % gx);
+        by = (int)((t / gx) % gy);
+        split = (int)(t / (gx * gy));
+    }
     int s = 0;
     for (int i = 1; i < P.nsrc; ++i)
         if (bx >= P.tile_begin[i]) s = i;
     const GSrc &S = P.src[s];
     int coff = 0;
     for (int i = 0; i < s; ++i) coff += P.src[i].C;
-    const int c0 = (bx - P.tile_begin[s]) * 32;          // channel tile of the member
+    const int c0 = (bx - P.tile_begin[s]) * CT;          // channel tile of the member
     const int co0 = by * 32;
-    const int kbeg = split * P.klen, kend = min(P.M, kbeg + P.klen);
-    int groups_left = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-    const int nsteps = (groups_left + WP_PG - 1) / WP_PG;
     const int H = P.Hv, W = P.Wv;                         // low-resolution frame
+    // K = pixels in blocks of 2 rows x 16 columns; this split's range of blocks
+    const int nbx = W / 16, nby = H / 2;
+    const int nblocks = P.B * nby * nbx, bps = (nblocks + P.S - 1) / P.S;
+    const int blk0 = split * bps;
+    const int nsteps = max(0, min(nblocks, blk0 + bps) - blk0);
 
-    // load slots: piece p = wave + 4 i; lanes 4 k .. 4 k + 3 fetch the four 16-byte chunks
-    // of pixel slot 16 p + k
-    unsigned v_off[WP_LPW];
-    int v_dy[WP_LPW], v_dx[WP_LPW], v_g[WP_LPW];
+    // load slots: piece p = wave + 4 i; a lane fetches one 16-byte chunk of one pixel slot
+    unsigned v_off[G::LPW];
+    int v_dy[G::LPW], v_dx[G::LPW];
+    bool v_on[G::LPW];
 #pragma unroll
-    for (int i = 0; i < WP_LPW; ++i) {
-        const int p = wave + 4 * i, q = lane & 3;
+    for (int i = 0; i < G::LPW; ++i) {
+        const int p = wave + 4 * i;
         v_off[i] = WP_OOB;
         v_dy[i] = v_dx[i] = 0;
-        v_g[i] = -1;                                      // dummy / unused slot
-        if (p < WP_XP) {
-            const int n = 16 * p + (lane >> 2);
-            if (n < WP_PG * WP_XSLOT) {
-                const int g = n / WP_XSLOT, rem = n - g * WP_XSLOT, r = rem / 18, c = rem - 18 * r;
-                v_g[i] = g;
+        v_on[i] = false;
+        if (p < G::XP) {
+            const int n = G::SPP * p + lane / G::LPS, q = lane % G::LPS;
+            if (n < WP_XSLOT) {
+                const int r = n / 18, c = n - 18 * r;
+                v_on[i] = true;
                 v_dy[i] = r - 1;
                 v_dx[i] = c - 1;
+                const int qq = q ^ (4 * wp_swz<CT>(n));
                 // the resource's base is shifted by (-1, -1): offsets stay non-negative
-                v_off[i] = (unsigned)((r * S.sy + c * S.sx + c0 + 8 * q) * 2);
+                v_off[i] = (unsigned)((r * S.sy + c * S.sx + c0 + 8 * qq) * 2);
             }
-        } else if (p < WP_XP + WP_GP) {
-            const int n = 16 * (p - WP_XP) + (lane >> 2);
-            const int g = n >> 6, ph = (n >> 4) & 3, c = n & 15;
-            v_g[i] = 2 + g;                               // 2, 3: gradient planes of group 0, 1
-            v_off[i] = (unsigned)(((ph >> 1) * P.g_py + (ph & 1) * P.g_px + c * P.g_sx + co0 + 8 * q) * 2);
+        } else if (p < G::XP + G::GP) {
+            const int n = 16 * (p - G::XP) + (lane >> 2), q = lane & 3;
+            const int ph = n >> 5, rr = (n >> 4) & 1, c = n & 15;
+            v_on[i] = true;
+            v_off[i] = (unsigned)(((ph >> 1) * P.g_py + (ph & 1) * P.g_px + rr * P.g_sy + c * P.g_sx + co0 +
+                                   8 * q) * 2);
         }
     }
     const __amdgpu_buffer_rsrc_t gres =
@@ -100,114 +136,99 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_patch_twins_kernel(const WGradP
     const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(S.p16 - ((long long)S.sy + S.sx)), 0, 0x7fffffff, 0x00020000);
 
-    int g_ox = kbeg % P.Wo, g_oy = (kbeg / P.Wo) % P.Ho, g_b = kbeg / (P.Wo * P.Ho);
+    int k_bx = blk0 % nbx, k_by = (blk0 / nbx) % nby, k_b = blk0 / (nbx * nby);
     auto issue = [&](int stage_idx) {
-        int a_so[WP_PG], b_so[WP_PG], gy[WP_PG], gx[WP_PG];
-        bool live[WP_PG];
-#pragma unroll
-        for (int g = 0; g < WP_PG; ++g) {
-            live[g] = groups_left > 0;
-            a_so[g] = __builtin_amdgcn_readfirstlane(
-                (int)(((long long)g_b * P.g_sb + (long long)g_oy * P.g_sy + (long long)g_ox * P.g_sx) * 2));
-            b_so[g] = __builtin_amdgcn_readfirstlane(
-                (int)(((long long)g_b * S.sb + (long long)g_oy * S.sy + (long long)g_ox * S.sx) * 2));
-            gy[g] = g_oy;
-            gx[g] = g_ox;
-            if (live[g]) {
-                --groups_left;
-                g_ox += BK;
-                if (g_ox >= P.Wo) {
-                    g_ox = 0;
-                    if (++g_oy == P.Ho) {
-                        g_oy = 0;
-                        ++g_b;
-                    }
-                }
+        const int oy = 2 * k_by, ox = 16 * k_bx;
+        const int a_so = __builtin_amdgcn_readfirstlane(
+            (int)(((long long)k_b * P.g_sb + (long long)oy * P.g_sy + (long long)ox * P.g_sx) * 2));
+        const int b_so = __builtin_amdgcn_readfirstlane(
+            (int)(((long long)k_b * S.sb + (long long)oy * S.sy + (long long)ox * S.sx) * 2));
+        if (++k_bx == nbx) {
+            k_bx = 0;
+            if (++k_by == nby) {
+                k_by = 0;
+                ++k_b;
             }
         }
-        unsigned char *st = smem + stage_idx * WP_STAGE;
+        unsigned char *st = smem + stage_idx * G::STAGE;
 #pragma unroll
-        for (int i = 0; i < WP_LPW; ++i) {
+        for (int i = 0; i < G::LPW; ++i) {
             const int p = wave + 4 * i;
             __attribute__((address_space(3))) void *dst =
                 (__attribute__((address_space(3))) void *)(st + p * 1024);
-            if (p < WP_XP) {
-                // (a piece may hold slots of both groups: the group is per lane)
-                const int g = v_g[i] == 1 ? 1 : 0;
-                const int y = (g ? gy[1] : gy[0]) + v_dy[i], x = (g ? gx[1] : gx[0]) + v_dx[i];
-                const bool ok = (v_g[i] >= 0) & (g ? live[1] : live[0]) & ((unsigned)y < (unsigned)H) &
-                                ((unsigned)x < (unsigned)W);
-                // per-lane group -> the group's base goes into the vector offset
-                const unsigned base = (unsigned)(g ? b_so[1] : b_so[0]);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(sres, dst, 16, ok ? v_off[i] + base : WP_OOB, 0, 0, 0);
-            } else if (p < WP_XP + WP_GP) {
-                const bool g1 = (p - WP_XP) >= WP_GP / 2;       // scalar: pieces 0-3 group 0, 4-7 group 1
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, (g1 ? live[1] : live[0]) ? v_off[i] : WP_OOB,
-                                                         g1 ? a_so[1] : a_so[0], 0, 0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, WP_OOB, 0, 0, 0);   // the dummy piece
+            if (p < G::XP) {
+                const bool ok = v_on[i] & ((unsigned)(oy + v_dy[i]) < (unsigned)H) &
+                                ((unsigned)(ox + v_dx[i]) < (unsigned)W);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sres, dst, 16, ok ? v_off[i] : WP_OOB, b_so, 0, 0);
+            } else {    // gradient planes (always inside the frame) and the padding pieces
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, v_on[i] ? v_off[i] : WP_OOB, a_so, 0, 0);
             }
         }
     };
 
-    f32x16 acc[4];          // tap t = 2 p + q of this wave's phase: D[co 32][ci 32]
+    f32x16 acc[4][G::NB];       // tap t = 2 p + q of this wave's phase, column block: D[co 32][ci 32]
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int nb = 0; nb < G::NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nb][r] = 0.f;
     const int lrow = lane & 31, lh = lane >> 5;
     const bool do_bias = P.dbias != nullptr && bx == 0;
     float bsum = 0.f;
     // transposed fragment reads (wgrad2_twins_kernel): group tg = lane >> 4 covers channels
     // 16 (tg & 1) .. and pixels 8 (tg >> 1) + 4 rd ..; lane 4 tq + tp of the group addresses
-    // pixel row tq, channels 4 tp .. 4 tp + 3.  Pixel rows are 64 bytes here.
+    // pixel row tq, channels 4 tp .. 4 tp + 3
     const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    const int frag = (8 * (tg >> 1) + tq) * 64 + 32 * (tg & 1) + 8 * tp;
+    const int kpix = 8 * (tg >> 1) + tq;            // this lane's pixel within a 16-pixel K step (lo read)
+    const int cbyte = 32 * (tg & 1) + 8 * tp;       // its bytes within a 32-channel block
 
     auto compute = [&](int u) {
-        const unsigned char *st = smem + u * WP_STAGE;
+        const unsigned char *st = smem + u * G::STAGE;
 #pragma unroll
-        for (int g = 0; g < WP_PG; ++g) {
-            const unsigned char *ga = st + WP_XP * 1024 + ((g * 4 + wave) * 16) * 64 + frag;
+        for (int rr = 0; rr < 2; ++rr) {            // the block's two pixel rows: one K step each
+            const unsigned char *ga = st + G::XP * 1024 + ((wave * 2 + rr) * 16 + kpix) * 64 + cbyte;
             const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)ga);
             const s16x4 ahi =
                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(ga + 4 * 64));
             const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
-            bf16x8 fb[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = pa + (t >> 1), c = pb + (t & 1);          // patch row / first patch column
-                const unsigned char *xb = st + ((g * WP_XSLOT + r * 18 + c)) * 64 + frag;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)xb);
-                const s16x4 hi =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(xb + 4 * 64));
-                fb[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
             if (do_bias) {
                 const s16x8 v = __builtin_bit_cast(s16x8, fa);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsum += __builtin_bit_cast(float, (unsigned)(unsigned short)v[e] << 16);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                // patch row rr + a + p, first patch column b + q
+                const int n_lo = (rr + pa + (t >> 1)) * 18 + pb + (t & 1) + kpix, n_hi = n_lo + 4;
+#pragma unroll
+                for (int nb = 0; nb < G::NB; ++nb) {
+                    const unsigned char *xl = st + n_lo * G::PXB + 64 * (nb ^ wp_swz<CT>(n_lo)) + cbyte;
+                    const unsigned char *xh = st + n_hi * G::PXB + 64 * (nb ^ wp_swz<CT>(n_hi)) + cbyte;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)xl);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)xh);
+                    const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t][nb], 0, 0, 0);
+                }
+            }
         }
     };
 
 #pragma unroll
-    for (int u = 0; u < WP_NS - 1; ++u)
+    for (int u = 0; u < G::NS - 1; ++u)
         if (u < nsteps) issue(u);
-    for (int s0 = 0; s0 < nsteps; s0 += WP_NS) {
+    for (int s0 = 0; s0 < nsteps; s0 += G::NS) {
 #pragma unroll
-        for (int u = 0; u < WP_NS; ++u) {
+        for (int u = 0; u < G::NS; ++u) {
             const int st = s0 + u;
             if (st < nsteps) {
-                if (st + WP_NS - 2 < nsteps) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WP_NS - 2) * WP_LPW) : "memory");
+                if (st + G::NS - 2 < nsteps) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::NS - 2) * G::LPW) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
-                if (st + WP_NS - 1 < nsteps) issue((u + WP_NS - 1) % WP_NS);
+                if (st + G::NS - 1 < nsteps) issue((u + G::NS - 1) % G::NS);
                 compute(u);
             }
         }
@@ -221,14 +242,16 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_patch_twins_kernel(const WGradP
     const size_t wsize = (size_t)P.Cout * 4 * P.Cin_tot;
     float *dW = P.dW + (size_t)slab * wsize;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const size_t col = (size_t)t * P.Cin_tot + coff + c0 + lrow;
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            dW[(size_t)co * 4 * P.Cin_tot + col] = acc[t][reg];
+        for (int nb = 0; nb < G::NB; ++nb) {
+            const size_t col = (size_t)t * P.Cin_tot + coff + c0 + 32 * nb + lrow;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                dW[(size_t)co * 4 * P.Cin_tot + col] = acc[t][nb][reg];
+            }
         }
-    }
 #endif
 }
 
@@ -243,7 +266,7 @@ bool wgrad_patch_shape_ok(const WGradParams &P)
     static const bool off = getenv("DVSOF_NO_WGRAD_PATCH") != nullptr;
     if (off || P.nph != 4 || P.ks != 2 || P.stride != 1 || P.up != UP_NONE) return false;
     if (P.ph_pad != 1 || P.pad != 1 || P.src_ph_stride != 0) return false;
-    if ((P.Cout & 31) || (P.Wo % BK) || P.Ho != P.Hv || P.Wo != P.Wv) return false;
+    if ((P.Cout & 31) || (P.Wo % 16) || (P.Ho & 1) || P.Ho != P.Hv || P.Wo != P.Wv) return false;
     // flat members (the 2-channel flow of a decoder stage) are not this kernel's: their
     // columns belong to the caller (dvsof_flow_fold_grads) or to the flat-member kernels
     int nvec = 0;
@@ -263,19 +286,38 @@ bool wgrad_patch_eligible(const WGradParams &P)
     return true;
 }
 
+// 64 input channels per workgroup halve the gradient planes' re-reads
+// (DVSOF_WGRAD_PATCH_CT=64 where every vector member allows it)
+static int wp_channel_tile(const WGradParams &P)
+{
+    static const int force = getenv("DVSOF_WGRAD_PATCH_CT") ? atoi(getenv("DVSOF_WGRAD_PATCH_CT")) : 0;
+    long long ct = 0;
+    for (int s = 0; s < P.nsrc; ++s) {
+        if (P.src[s].flat) continue;
+        if (P.src[s].C & 63) return 32;
+        ct += P.src[s].C / 64;
+    }
+    if (force == 32 || force == 64) return force;
+    (void)ct;
+    // measured (batch 8, the four decoder stages): 32 wins everywhere -- the slab bound on the
+    // K splits leaves the 64-channel form with 224-256 workgroups
+    return 32;
+}
+
 // K splits for this kernel: enough workgroups for two per CU; a slab is a whole folded-size
 // gradient, so no more splits than that takes (<= 64, the workspace bound of wgrad_splits)
 int wgrad_patch_splits(const WGradParams &P)
 {
+    const int CT = wp_channel_tile(P);
     long long tiles = (long long)(P.Cout / 32);
     long long ct = 0;
     for (int s = 0; s < P.nsrc; ++s)
-        if (!P.src[s].flat) ct += P.src[s].C / 32;
+        if (!P.src[s].flat) ct += P.src[s].C / CT;
     tiles *= ct;
-    const long long groups = ((long long)P.M + BK - 1) / BK;
+    const long long blocks = (long long)P.B * (P.Hv / 2) * (P.Wv / 16);
     static const int target = getenv("DVSOF_WGRAD_PATCH_WGS") ? atoi(getenv("DVSOF_WGRAD_PATCH_WGS")) : 512;
     long long S = (target + tiles - 1) / tiles;
-    const long long maxS = groups / (2 * WP_PG) > 0 ? groups / (2 * WP_PG) : 1;    // >= 2 stages per split
+    const long long maxS = blocks / 2 > 0 ? blocks / 2 : 1;    // >= 2 stages per split
     if (S > maxS) S = maxS;
     // a slab is a whole phase-form gradient: at most ~32 MB of partial sums per layer
     const long long slab_bytes = 4LL * P.Cout * 4 * P.Cin_tot * 4;
@@ -288,24 +330,32 @@ int wgrad_patch_splits(const WGradParams &P)
     return (int)S;
 }
 
-int wgrad_patch_launch(const WGradParams &P0, hipStream_t st)
+template <int CT>
+static int wp_launch(WGradParams &P, hipStream_t st)
 {
-    WGradParams P = P0;
     int nt = 0;
     for (int s = 0; s < P.nsrc; ++s) {
         P.tile_begin[s] = nt;
-        if (!P.src[s].flat) nt += P.src[s].C / 32;
+        if (!P.src[s].flat) nt += P.src[s].C / CT;
     }
     P.tile_begin[P.nsrc] = nt;
-    constexpr size_t LDS = (size_t)WP_NS * WP_STAGE;
+    constexpr size_t LDS = (size_t)WPGeom<CT>::NS * WPGeom<CT>::STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_patch_twins_kernel,
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_patch_twins_kernel<CT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid(nt, P.Cout / 32, P.S);
-    hipLaunchKernelGGL(wgrad_patch_twins_kernel, grid, dim3(CONV_NT), LDS, st, P);
+    static const bool xcd_off = getenv("DVSOF_WGRAD_XCD") && atoi(getenv("DVSOF_WGRAD_XCD")) == 0;
+    P.xcd = xcd_off ? 0 : 1;
+    hipLaunchKernelGGL(wgrad_patch_twins_kernel<CT>, grid, dim3(CONV_NT), LDS, st, P);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
+}
+
+int wgrad_patch_launch(const WGradParams &P0, hipStream_t st)
+{
+    WGradParams P = P0;
+    return wp_channel_tile(P) == 64 ? wp_launch<64>(P, st) : wp_launch<32>(P, st);
 }

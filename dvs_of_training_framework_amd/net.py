@@ -141,6 +141,8 @@ class Model(nn.Module):
     def forward(self, events, timestamps, sample_idx, imsize, raw=True,
                 intermediate=False, batch_size=None):
         batch = batch_size or int(sample_idx[-1]) + 1
+        if raw and torch.is_grad_enabled() and timestamps.is_cuda:
+            self.predictor.mark_step_begin(timestamps.device)
         start, stop, t0, t1 = self._select(timestamps, sample_idx, batch)
         h, w, hp, wp = self._padded(imsize)
         if raw:

@@ -17,6 +17,7 @@ _lib.register('dvsof_adamw_chunk_elems', _i, [])
 _lib.register('dvsof_adamw_step', _i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f,
                                        _i, _i, _vp])
 _lib.register('dvsof_adamw_dynamic', None, [_f, _f, _f, _i, ctypes.POINTER(_f)])
+_lib.register('dvsof_adamw_set_dynamic', _i, [_vp, ctypes.POINTER(_f), _i, _vp])
 _lib.register('dvsof_adamw_step_dyn', _i, [_vp, _vp, _vp, _i, _vp, _f, _f, _f,
                                            _f, _i, _vp])
 _lib.register('dvsof_radam_step', _i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _f,
@@ -210,21 +211,14 @@ class FusedAdamW(_FusedBase):
         if getattr(self, '_dyn', None) is None:
             ng = len(self.param_groups)
             self._dyn = torch.zeros(ng, 4, dtype=torch.float32, device=device)
-            # ring of pinned staging rows: an async copy reads its row when the
-            # stream gets there, so a row is rewritten only after its copy's
-            # event has completed (the host runs several steps ahead)
-            self._dyn_ring = [(torch.zeros(ng, 4, dtype=torch.float32).pin_memory(),
-                               torch.cuda.Event()) for _ in range(64)]
-            self._dyn_next = 0
         self._use_dyn = True
 
     def advance(self):
         """Before every replay: count the step and refresh {lr, lr/bc1,
-        sqrt(bc2)} of every group with one small asynchronous copy."""
-        host, done = self._dyn_ring[self._dyn_next]
-        self._dyn_next = (self._dyn_next + 1) % len(self._dyn_ring)
-        done.synchronize()      # the copy that last read this row (64 steps ago)
-        buf = (ctypes.c_float * 3)()
+        sqrt(bc2)} of every group (one tiny kernel carrying the values as
+        arguments: dvsof_adamw_set_dynamic)."""
+        ng = len(self.param_groups)
+        buf, rows = (ctypes.c_float * 3)(), (ctypes.c_float * (4 * ng))()
         for gi, group in enumerate(self.param_groups):
             steps = set()
             for p in group['params']:
@@ -235,9 +229,9 @@ class FusedAdamW(_FusedBase):
             b1, b2 = group['betas']
             _lib.lib().dvsof_adamw_dynamic(float(group['lr']), float(b1),
                                            float(b2), steps.pop(), buf)
-            host[gi, 0], host[gi, 1], host[gi, 2] = buf[0], buf[1], buf[2]
-        self._dyn.copy_(host, non_blocking=True)
-        done.record()
+            rows[4 * gi], rows[4 * gi + 1], rows[4 * gi + 2] = buf[0], buf[1], buf[2]
+        _lib.check(_lib.lib().dvsof_adamw_set_dynamic(
+            self._dyn.data_ptr(), rows, 4 * ng, _lib.stream()), 'dvsof_adamw_set_dynamic')
 
     def end_capture(self):
         """Back to eager steps (the table stays: a graph may still use it)."""

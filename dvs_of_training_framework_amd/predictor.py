@@ -112,8 +112,30 @@ class _PredictorFn(torch.autograd.Function):
         # buffers it is about to reuse).
         main = torch.cuda.current_stream(dev)
         side = module._wgrad_stream(dev) if want_grad else None
+        begin = module._take_step_begin()
         if side is not None:
-            side.wait_stream(main)
+            # ... or, when the caller marked the start of the step (mark_step_begin, ahead
+            # of the voxeliser), only for what preceded THAT: nothing made here reads the
+            # event volume, so the forms run beside the voxeliser and the first layers
+            if begin is not None:
+                side.wait_event(begin)
+            else:
+                side.wait_stream(main)
+
+        # bf16-twins mode: the twins of the weights that are used as they are
+        # (stride-2 encoder layers, direct residual layers) in ONE launch; the
+        # twins of prepared forms come from the kernels that make the forms
+        raw16, raw16_ready = {}, None
+        if twins:
+            raws = [e_[0] for e_ in enc] + [r_[j] for r_ in res for j in (0, 2)]
+            # on the second stream when there is one (16 us off the forward's lane): the
+            # first layer does not read them, the main stream waits before the second
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                raw16 = {id(w_): t_ for w_, t_ in
+                         zip(raws, C.to_bf16_many([_phys(w_) for w_ in raws]))}
+                if side is not None:
+                    raw16_ready = torch.cuda.Event()
+                    raw16_ready.record(side)
 
         # Prepared FORWARD forms (Winograd-domain weights of the residual
         # layers, sub-pixel phase kernels of the decoder) are not needed
@@ -171,20 +193,6 @@ class _PredictorFn(torch.autograd.Function):
                 pre_ready = torch.cuda.Event()
                 pre_ready.record(side)
         waited, waited16 = [False], [False]
-        # bf16-twins mode: the twins of the weights that are used as they are
-        # (stride-2 encoder layers, direct residual layers) in ONE launch; the
-        # twins of prepared forms come from the kernels that make the forms
-        raw16, raw16_ready = {}, None
-        if twins:
-            raws = [e_[0] for e_ in enc] + [r_[j] for r_ in res for j in (0, 2)]
-            # on the second stream when there is one (16 us off the forward's lane): the
-            # first layer does not read them, the main stream waits before the second
-            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                raw16 = {id(w_): t_ for w_, t_ in
-                         zip(raws, C.to_bf16_many([_phys(w_) for w_ in raws]))}
-                if side is not None:
-                    raw16_ready = torch.cuda.Event()
-                    raw16_ready.record(side)
 
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
                 residual=None):
@@ -552,6 +560,21 @@ class Predictor(nn.Module):
         if key not in _SIDE_STREAMS:
             _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
         return _SIDE_STREAMS[key]
+
+    def mark_step_begin(self, dev):
+        """Called by the model wrapper before it voxelises: the second stream's
+        work of the coming forward (weight twins, prepared forms) depends on the
+        optimizer's update only, and may start HERE instead of behind the
+        voxeliser (78 us of small kernels off the forward's lane at batch 8)."""
+        if os.environ.get('DVSOF_NO_STEP_BEGIN') or self._wgrad_stream(dev) is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._step_begin = ev
+
+    def _take_step_begin(self):
+        ev, self._step_begin = getattr(self, '_step_begin', None), None
+        return ev
 
     def _extra_streams(self, dev):
         n = int(os.environ.get('DVSOF_WGRAD_STREAMS', '1')) - 1

@@ -503,11 +503,17 @@ int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes,
  * rate (LambdaLR, train_flownet.py:91-109) and the bias corrections -- is read
  * from `dyn`, device float[3] = {lr, lr/(1-beta1^t), sqrt(1-beta2^t)}.
  * dvsof_adamw_dynamic fills a HOST float[3] with exactly the values
- * dvsof_adamw_step would use (the caller copies it to `dyn` before each replay),
+ * dvsof_adamw_step would use (the caller puts it into `dyn` before each replay:
+ * dvsof_adamw_set_dynamic),
  * so both entry points give bit-identical parameters.
  */
 void dvsof_adamw_dynamic(float lr, float beta1, float beta2, int step,
                          float *host_out3);
+/* host_values[n] -> dyn[n] (device) in stream order, the values travelling as
+ * kernel arguments: no copy engine, no fence in front of the step's first
+ * kernel; host_values may be reused as soon as the call returns */
+int dvsof_adamw_set_dynamic(float *dyn, const float *host_values, int n,
+                            void *stream);
 int dvsof_adamw_step_dyn(const uint64_t *ptrs, const int64_t *sizes,
                          const int32_t *chunks, int num_chunks,
                          const float *dyn, float beta1, float beta2, float eps,
@@ -604,13 +610,21 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
  *                 to dvsof_exec_launch); nodes are split into at most
  *                 1 + n_side chains, one event per dependency across chains
  *   dvsof_exec_calibrate  runs the step ONCE on `stream` alone with a timing
- *                       event per kernel, waits for it (the only host
- *                       synchronisation of the executor) and re-plans the
- *                       lanes: lane 0 = longest path by measured time, so the
- *                       chain that bounds the step never changes queues (a
- *                       cross-queue dependency costs ~13 us); before it a
- *                       greedy chain split is in effect.  It IS a step: same
- *                       kernels, same results as dvsof_exec_launch
+ *                       event per kernel, waits for it and re-plans the lanes
+ *                       from the measured durations.  Three plans: "paths"
+ *                       (lane 0 = longest path by time, the rest on the last
+ *                       lane), "list" (list scheduling by remaining path
+ *                       length, which also fixes the launch order; marks keep
+ *                       their capture order) and "chain" (the greedy split in
+ *                       effect before calibration).  The next 6 calls of
+ *                       dvsof_exec_launch are real steps under each plan in
+ *                       turn, timed on the device (the host waits for the
+ *                       previous step before each of them); the fastest plan
+ *                       stays.  DVSOF_EXEC_PLAN=paths|list|chain fixes one.
+ *                       It IS a step: same kernels, same results as
+ *                       dvsof_exec_launch -- under every plan
+ *   dvsof_exec_plan     name of the plan in effect; settled = 0 while plans
+ *                       are still being tried
  *   dvsof_exec_launch   side lanes start behind `stream`, `stream` continues
  *                       behind every lane; nothing else synchronises
  *   dvsof_exec_node     node i in launch order: lane, measured us, number of
@@ -652,6 +666,7 @@ int dvsof_exec_calibrate(void *exec, void *stream);
 int dvsof_exec_launch(void *exec, void *stream);
 int dvsof_exec_node(void *exec, int i, int *lane, float *us, int *n_waits,
                     char *name, int name_len);
+int dvsof_exec_plan(void *exec, char *name, int name_len, int *settled);
 int dvsof_exec_destroy(void *exec);
 
 #ifdef __cplusplus

@@ -174,6 +174,10 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     dict(B=3, H=16, W=16, src=[(64, 'nhwc'), (32, 'nhwc')], Cout=64, up=True),
     dict(B=2, H=8, W=32, src=[(32, 'nhwc')], Cout=32, up=True),
     dict(B=1, H=16, W=48, src=[(96, 'nhwc'), (32, 'nhwc')], Cout=96, up=True),
+    # 64 input channels per workgroup (members of 64 | C and >= 512 workgroups): 128-byte
+    # pixel slots with the swizzled halves; 144 blocks over 64 splits (empty splits write zeros)
+    dict(B=4, H=32, W=32, src=[(128, 'nhwc'), (128, 'nhwc')], Cout=64, up=True),
+    dict(B=3, H=32, W=48, src=[(64, 'nhwc'), (192, 'nhwc'), (2, 'nchw')], Cout=64, up=True),
 ])
 def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
     """mfma mode 3: the vector members' weight gradient streams the bf16 TWINS

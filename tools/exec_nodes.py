@@ -17,9 +17,12 @@ def main():
     h = bench.Harness(a, 0, torch.device('cuda', 0))
     for _ in range(6):
         h.step()
+    h.settle()
     torch.cuda.synchronize()
     ex = h.captured.executor
-    print(f'{ex.kernels} kernels, lanes {ex.lane_kernels}, {ex.events} events, {ex.waits} waits')
+    ex._info()
+    print(f'{ex.kernels} kernels, lanes {ex.lane_kernels}, {ex.events} events, {ex.waits} waits, '
+          f'plan {ex.plan()}')
     tot = [0.0] * ex.lanes
     for i, (lane, us, nw, name) in enumerate(ex.nodes()):
         name = re.sub(r'\(anonymous namespace\)::', '', name).replace('void ', '').split('(')[0][:60]
