@@ -34,6 +34,11 @@ size_t first_wgrad_workspace_floats(int B, int C, int H, int W);
 int first_wgrad_launch(const float *x, int B, int C, int H, int W, const float *gout, float *dW,
                        float *dbias, float *ws, size_t ws_floats, hipStream_t st);
 
+// fwd_patch.hip: forward of the finest decoder stage in the bf16-twins mode (patch in LDS,
+// weights in registers)
+bool fwd_patch_eligible(const GConvParams &P);
+int fwd_patch_launch(const GConvParams &P, hipStream_t st);
+
 namespace {
 
 bool is_first_layer(const dvsof_conv_desc_t *d)
@@ -731,6 +736,8 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     }
     if (is_wino(d))   // `weight` is the prepared U[16][Cout][Ctot]
         return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
+    if (is_subpixel(d) && fwd_patch_eligible(P))   // finest decoder stage on the bf16 twins: fwd_patch.hip
+        return fwd_patch_launch(P, as_stream(stream));
     return gconv_launch(P, 0, as_stream(stream));
 }
 

@@ -216,6 +216,52 @@ def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
     close(dw3, dwx, BF16_RTOL)
 
 
+@pytest.mark.parametrize('B,H,W,act,cls,want_z', [
+    (1, 2, 16, 'relu', False, False),       # one block: every patch row / column border at once
+    (2, 8, 16, 'relu', True, True),         # border-class bias of a folded flow member, z copy
+    (3, 10, 48, 'mish', True, True),        # strips shared between workgroups, ragged last range
+    (8, 64, 64, 'relu', True, False),       # 512 persistent workgroups x 4 blocks
+    (8, 128, 128, 'relu', False, False),    # the benchmark's finest stage: 8 blocks per workgroup
+])
+def test_finest_decoder_forward_on_bf16_twins_equals_the_operand_mode(B, H, W, act, cls, want_z):
+    """csrc/fwd_patch.hip (mode 3, cat[x 64, skip 64] -> 32, sub-pixel phases):
+    input patch resident in LDS, weights in registers.  Mode 1 rounds the same
+    f32 values to bf16 in registers, so both multiply identical operands: equal
+    up to f32 summation order; the bf16 twin of y is y rounded; and both stay
+    within the bf16 bound of the exact layer."""
+    from dvs_of_training_framework_amd import conv as C
+    g = torch.Generator().manual_seed(B * 131 + H)
+    x = nhwc(torch.randn(B, 64, H, W, generator=g))
+    sk = nhwc(torch.randn(B, 64, H, W, generator=g))
+    w = wphys(torch.randn(32, 128, 3, 3, generator=g) / (128 * 9) ** 0.5)
+    b = torch.randn(32, generator=g).cuda()
+    b_cls = (torch.randn(9, 32, generator=g).cuda() * 0.3) if cls else None
+    a = {'relu': C.ACT_RELU, 'mish': C.ACT_MISH}[act]
+
+    def run(mode):
+        twins = mode == C.MFMA_BF16_TWINS
+        srcs = [(t, 64, C.NHWC, t.to(torch.bfloat16) if twins else None) for t in (x, sk)]
+        d = C.make_desc(srcs, B, H, W, 32, 3, 1, 1, True, a, mode)
+        d._keep = srcs
+        if twins:
+            w_f, _, w_f16, _ = C.prepare(d, w, False, want16=True)
+        else:
+            (w_f, _), w_f16 = C.prepare(d, w, False), None
+        y, z = C.conv_fwd(d, w_f, b, 'cuda', None, want_z=want_z, weight16=w_f16, bias_cls=b_cls)
+        torch.cuda.synchronize()
+        return y, z, d._y16
+    y1, z1, _ = run(C.MFMA_BF16)
+    y3, z3, y16 = run(C.MFMA_BF16_TWINS)
+    close(y3, y1, 1e-5)
+    if want_z:
+        close(z3, z1, 1e-5)
+    assert torch.equal(y16.view(y3.shape), y3.to(torch.bfloat16))
+    y3b, _, _ = run(C.MFMA_BF16_TWINS)
+    assert torch.equal(y3, y3b)
+    yx, _, _ = run(C.MFMA_F32)
+    close(y3, yx, BF16_RTOL)
+
+
 @pytest.mark.parametrize('B,H,W,Cx,Cs,Cout', [
     (2, 8, 8, 32, 32, 32),
     (3, 6, 10, 64, 32, 64),          # odd frame sides, unequal members
