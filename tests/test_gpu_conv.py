@@ -65,6 +65,11 @@ CASES = [
     dict(B=1, H=8, W=8, src=[(16, 'nchw')], Cout=64, stride=2, first=True),
     dict(B=1, H=8, W=8, src=[(3, 'nchw')], Cout=64, stride=2, first=True),
     dict(B=8, H=128, W=128, src=[(5, 'nchw')], Cout=64, stride=2, first=True),   # 256 tiles: one per group
+    # decoder stages whose weight gradient takes the patch-resident f32 kernel
+    # (csrc/wgrad_patch.hip): 64 input channels per workgroup (swapped halves of odd patch
+    # slots), 144 blocks over 64 splits with a flat member beside the vector members
+    dict(B=4, H=32, W=32, src=[(128, 'nhwc'), (128, 'nhwc')], Cout=64, up=True),
+    dict(B=3, H=32, W=48, src=[(64, 'nhwc'), (192, 'nhwc'), (2, 'nchw')], Cout=64, up=True),
 ]
 
 
