@@ -70,6 +70,11 @@ CASES = [
     # slots), 144 blocks over 64 splits with a flat member beside the vector members
     dict(B=4, H=32, W=32, src=[(128, 'nhwc'), (128, 'nhwc')], Cout=64, up=True),
     dict(B=3, H=32, W=48, src=[(64, 'nhwc'), (192, 'nhwc'), (2, 'nchw')], Cout=64, up=True),
+    # the finest decoder stage with its flow member folded away (two members of 64 -> 32):
+    # forward by csrc/fwd_patch.hip (weights in registers, patch in LDS)
+    dict(B=1, H=2, W=16, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
+    dict(B=3, H=10, W=48, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True, act='mish'),
+    dict(B=2, H=64, W=64, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
 ]
 
 
@@ -183,6 +188,11 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     # pixel slots with the swizzled halves; 144 blocks over 64 splits (empty splits write zeros)
     dict(B=4, H=32, W=32, src=[(128, 'nhwc'), (128, 'nhwc')], Cout=64, up=True),
     dict(B=3, H=32, W=48, src=[(64, 'nhwc'), (192, 'nhwc'), (2, 'nchw')], Cout=64, up=True),
+    # the finest decoder stage with its flow member folded away (two members of 64 -> 32):
+    # forward by csrc/fwd_patch.hip (weights in registers, patch in LDS)
+    dict(B=1, H=2, W=16, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
+    dict(B=3, H=10, W=48, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True, act='mish'),
+    dict(B=2, H=64, W=64, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
 ])
 def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
     """mfma mode 3: the vector members' weight gradient streams the bf16 TWINS
