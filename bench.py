@@ -44,8 +44,12 @@ TILE_SHAPES = {
 }
 
 
-def kernel_name(family, tile, gen, wino=0):
+def kernel_name(family, tile, gen, wino=0, patch=0, dtype='f32'):
     """Name as rocprofv3 reports it (kernel template + tile shape)."""
+    if patch:   # csrc/fwd_patch.hip, csrc/wgrad_patch.hip: patch-resident decoder kernels
+        k = 'f32' if dtype == 'f32' else 'twins'
+        return (f'fwd_patch_{k}_kernel 2x16 px blocks' if family == 'gconv'
+                else f'wgrad_patch_{k}_kernel 32 cout x 16 views + subpixel_fold')
     if wino:
         # input / gradient transforms + NG component GEMMs + output transform
         ng = (wino + 2) ** 2
@@ -296,7 +300,8 @@ def measure_roofline(h, step_ms, steps=3):
             e0.record()
             out = fn(desc, *args, **kw)
             e1.record()
-            records.append((kernel_name(family, tile, gen, wino), conv_flops(desc, kind),
+            patch = lib.dvsof_conv2d_last_patch(kind) if kind != 1 else 0
+            records.append((kernel_name(family, tile, gen, wino, patch, h.a.dtype), conv_flops(desc, kind),
                             e0, e1, executed_flops(desc, kind)))
             return out
         return inner

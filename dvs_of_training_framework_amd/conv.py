@@ -54,6 +54,7 @@ _lib.register('dvsof_to_bf16', _i, [_vp, _vp, _sz, _vp])
 _lib.register('dvsof_act_bwd', _i, [_vp, _vp, _i, _vp, _sz, _vp])
 _lib.register('dvsof_conv2d_tile_id', _i, [_P(ConvDesc), _i])
 _lib.register('dvsof_conv2d_kernel_generation', _i, [_P(ConvDesc), _i])
+_lib.register('dvsof_conv2d_last_patch', _i, [_i])
 _lib.register('dvsof_conv2d_fwd_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_dgrad_weight_elems', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_prepare', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp])

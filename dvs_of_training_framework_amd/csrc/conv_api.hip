@@ -34,6 +34,10 @@ size_t first_wgrad_workspace_floats(int B, int C, int H, int W);
 int first_wgrad_launch(const float *x, int B, int C, int H, int W, const float *gout, float *dW,
                        float *dbias, float *ws, size_t ws_floats, hipStream_t st);
 
+// set by the launches below / read by dvsof_conv2d_last_patch (profiling tools)
+static thread_local int t_last_patch[3] = {0, 0, 0};
+void conv_note_patch(int kind) { t_last_patch[kind] = 1; }
+
 // fwd_patch.hip: forward of the finest decoder stage in the bf16-twins mode (patch in LDS,
 // weights in registers)
 bool fwd_patch_eligible(const GConvParams &P);
@@ -663,6 +667,7 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
                      const float *residual, float *y, float *z, void *stream)
 {
     int Ctot, Ho, Wo;
+    t_last_patch[0] = 0;
     if (!desc_ok(d, Ctot, Ho, Wo) || !weight || !y) return DVSOF_EINVAL;
     if (is_first_layer(d) && !residual)     // exact f32 in every operand mode
         return first_fwd_launch(d->src[0].p, d->B, Ctot, d->H, d->W, weight, bias, d->act, y, z,
@@ -736,8 +741,10 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     }
     if (is_wino(d))   // `weight` is the prepared U[16][Cout][Ctot]
         return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
-    if (is_subpixel(d) && fwd_patch_eligible(P))   // finest decoder stage on the bf16 twins: fwd_patch.hip
+    if (is_subpixel(d) && fwd_patch_eligible(P)) {  // finest decoder stage: fwd_patch.hip
+        t_last_patch[0] = 1;
         return fwd_patch_launch(P, as_stream(stream));
+    }
     return gconv_launch(P, 0, as_stream(stream));
 }
 
@@ -911,6 +918,7 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
                        void *ws, size_t ws_bytes, void *stream)
 {
     int Ctot, Ho, Wo;
+    t_last_patch[2] = 0;
     if (!desc_ok(d, Ctot, Ho, Wo) || !gout || !dweight) return DVSOF_EINVAL;
     if (is_transposed(d)) {
         if (dbias && d->Cout > 256) return DVSOF_EINVAL;
@@ -1091,6 +1099,11 @@ int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *d, int kind)
         if (!g.flat) return (g.C % BK == 0) ? 2 : 1;
     }
     return 1;
+}
+
+int dvsof_conv2d_last_patch(int kind)
+{
+    return (kind == 0 || kind == 2) ? t_last_patch[kind] : 0;
 }
 
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)

@@ -45,7 +45,8 @@ constexpr int FP_MEMB = FP_SLOTS * 128;     // bytes of one member's patch (9 pi
 constexpr int FP_PIECES = 20;               // 18 + 2 padding pieces: every wave issues 5 loads
 constexpr int FP_LPW = FP_PIECES / 4;
 constexpr int FP_STAGE = FP_PIECES * 1024;
-constexpr int FP_NS = 4;
+constexpr int FP_NS = 3;
+constexpr int FP_XT = 4 * 4096;                // a 32 x 32 f32 output tile per wave (epilogue transpose)
 constexpr unsigned FP_OOB = 0x80000000u;
 
 __device__ __forceinline__ int fp_key(int slot) { return (slot >> 1) & 7; }
@@ -146,12 +147,10 @@ __global__ __launch_bounds__(CONV_NT) void fwd_patch_twins_kernel(const GConvPar
     // ---- this lane's pixel of a block (B operand column / D column) and its output channels
     const int prr = lrow >> 4, pcc = lrow & 15;
     const GDst &D = P.dst[0];
-    f32x4 bias4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        bias4[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (P.bias) bias4[g] = *(const f32x4 *)(P.bias + 8 * g + 4 * lh);
-    }
+    const int ecq = lane & 7;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias) bias4 = *(const f32x4 *)(P.bias + 4 * ecq);
+    unsigned char *xtile = smem + FP_NS * FP_STAGE + wave * 4096;
     int c_by = blk0 % nby, c_bx = (blk0 / nby) % nbx, c_b = blk0 / (nby * nbx);
 
     auto compute = [&](int u) {
@@ -173,29 +172,37 @@ __global__ __launch_bounds__(CONV_NT) void fwd_patch_twins_kernel(const GConvPar
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(t * 2 + m) * 4 + s], xb, acc, 0, 0, 0);
                 }
         }
-        // ---- epilogue: acc[4 g + e] = channel 8 g + 4 lh + e of pixel (prr, pcc)
-        const int oy = 2 * c_by + prr, ox = 16 * c_bx + pcc;
-        const long long o = (long long)c_b * D.sb + (long long)oy * D.sy + (long long)ox * D.sx +
-                            (long long)pa * D.ph_y + (long long)pb * D.ph_x + 4 * lh;
-        int cls = 0;
-        if (P.bias_cls) {
-            const int Y = 2 * oy + pa, X = 2 * ox + pb;
-            cls = 3 * (Y == 0 ? 1 : Y == P.out_H - 1 ? 2 : 0) + (X == 0 ? 1 : X == P.out_W - 1 ? 2 : 0);
-        }
+        // ---- epilogue through the wave's own LDS tile [pixel 32][channel 32] (16-byte chunks
+        // XOR-swizzled by pixel & 7): acc[4 g + e] = channel 8 g + 4 lh + e of pixel lrow goes
+        // in, lane = (pixel 8 r + (lane >> 3), chunk lane & 7) comes out -- 8 lanes store one
+        // pixel's 128 bytes (and 64 bytes of the twin) instead of 64 lanes 16 bytes 256 B apart
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            v += bias4[g];
-            if (cls) v += *(const f32x4 *)(P.bias_cls + cls * FP_N + 8 * g + 4 * lh);
-            if (ZOUT) *(f32x4 *)(P.zout + o + 8 * g) = v;
+            const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *(f32x4 *)(xtile + lrow * 128 + (((2 * g + lh) ^ (lrow & 7)) << 4)) = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int px = 8 * r + (lane >> 3);
+            f32x4 v = *(const f32x4 *)(xtile + px * 128 + ((ecq ^ (px & 7)) << 4));
+            const int oy = 2 * c_by + (px >> 4), ox = 16 * c_bx + (px & 15);
+            const long long o = (long long)c_b * D.sb + (long long)oy * D.sy + (long long)ox * D.sx +
+                                (long long)pa * D.ph_y + (long long)pb * D.ph_x + 4 * ecq;
+            v += bias4;
+            if (P.bias_cls) {
+                const int Y = 2 * oy + pa, X = 2 * ox + pb;
+                const int cls = 3 * (Y == 0 ? 1 : Y == P.out_H - 1 ? 2 : 0) + (X == 0 ? 1 : X == P.out_W - 1 ? 2 : 0);
+                if (cls) v += *(const f32x4 *)(P.bias_cls + cls * FP_N + 4 * ecq);
+            }
+            if (ZOUT) *(f32x4 *)(P.zout + o) = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], P.act);
-            *(f32x4 *)(D.p + o + 8 * g) = v;
+            *(f32x4 *)(D.p + o) = v;
             if (TWIN) {
                 s16x4 h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = (short)bf16_bits(v[e]);
-                *(s16x4 *)(D.p16 + o + 8 * g) = h;
+                *(s16x4 *)(D.p16 + o) = h;
             }
         }
         if (++c_by == nby) {
@@ -207,9 +214,10 @@ __global__ __launch_bounds__(CONV_NT) void fwd_patch_twins_kernel(const GConvPar
         }
     };
 
-    // ---- ring.  vmcnt counts loads AND stores in order: behind the loads of stage s come
-    // S(s-3) L(s+1) S(s-2) L(s+2) S(s-1) -- fewer stores for the first three stages
+    // ---- ring of 3.  vmcnt counts loads AND stores in order: behind the loads of stage s come
+    // S(s-2) L(s+1) S(s-1) -- fewer stores for the first two stages
     constexpr int ST = (ZOUT ? 4 : 0) + 4 + (TWIN ? 4 : 0);
+    static_assert(FP_NS == 3, "the waits below are written for a ring of 3");
 #pragma unroll
     for (int u = 0; u < FP_NS - 1; ++u)
         if (u < nsteps) issue(u);
@@ -218,15 +226,13 @@ __global__ __launch_bounds__(CONV_NT) void fwd_patch_twins_kernel(const GConvPar
         for (int u = 0; u < FP_NS; ++u) {
             const int st = s0 + u;
             if (st < nsteps) {
-                if (st + FP_NS - 2 < nsteps) {
-                    if (st >= 3) {
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FP_LPW + 3 * ST) : "memory");
-                    } else if (st == 2) {
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FP_LPW + 2 * ST) : "memory");
+                if (st + 1 < nsteps) {
+                    if (st >= 2) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FP_LPW + 2 * ST) : "memory");
                     } else if (st == 1) {
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FP_LPW + 1 * ST) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FP_LPW + ST) : "memory");
                     } else {
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FP_LPW) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FP_LPW) : "memory");
                     }
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -553,7 +559,7 @@ bool fwd_patch_eligible(const GConvParams &P)
 template <bool TWIN, bool ZOUT>
 static int fp_launch(const GConvParams &P, int nblocks, int bpw, int grid, hipStream_t st)
 {
-    constexpr size_t LDS = (size_t)FP_NS * FP_STAGE;
+    constexpr size_t LDS = (size_t)FP_NS * FP_STAGE + FP_XT;
     static bool attr_set = false;
     if (!attr_set) {
         DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)fwd_patch_twins_kernel<TWIN, ZOUT>,

@@ -895,6 +895,7 @@ bool wgrad_patch_shape_ok(const WGradParams &P);
 bool wgrad_patch_eligible(const WGradParams &P);
 int wgrad_patch_splits(const WGradParams &P);
 int wgrad_patch_launch(const WGradParams &P, hipStream_t st);
+void conv_note_patch(int kind);     // conv_api.hip
 
 // Number of K splits used for this problem (deterministic in the shape).
 int wgrad_splits(const WGradParams &P0, int *tile_out)
@@ -957,8 +958,12 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
                 P.dbias = direct ? dbias : bias_part;
                 bias_in_kernel = true;
             }
-            rc = (!direct && wgrad_patch_eligible(P)) ? wgrad_patch_launch(P, st)
-                                                      : wgrad2_launch(P, tile, nt, st);
+            if (!direct && wgrad_patch_eligible(P)) {
+                conv_note_patch(2);
+                rc = wgrad_patch_launch(P, st);
+            } else {
+                rc = wgrad2_launch(P, tile, nt, st);
+            }
             P.dbias = nullptr;
         }
         if (rc) return rc;

@@ -419,6 +419,12 @@ int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *desc, int kind);
  * of <= 16 channels, 3x3 stride 2 pad 1, 64 outputs, even frame sides; forward
  * and weight gradient, exact f32 in every operand mode). */
 int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *desc, int kind);
+/* 1 when the calling thread's LAST dvsof_conv2d_fwd (kind 0) / dvsof_conv2d_wgrad
+ * (kind 2) ran a patch-resident decoder kernel (csrc/fwd_patch.hip,
+ * csrc/wgrad_patch.hip) -- the choice depends on operand mode, twins and
+ * pointer alignment, which the descriptor alone does not fix (profiling tools:
+ * bench.py names its roofline groups with it) */
+int dvsof_conv2d_last_patch(int kind);
 
 /* wt[ci][k*k-1-tap][co] = w[co][tap][ci] */
 int dvsof_weight_flip_transpose(const float *w, float *wt, int Cout, int ksize,
