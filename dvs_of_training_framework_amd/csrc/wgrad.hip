@@ -947,7 +947,7 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
     for (int s = 0; s < P.nsrc; ++s) any_vec = any_vec || !P.src[s].flat;
     int want_flat = -1;  // v1 MFMA tiles for everything ...
     int rc = DVSOF_OK;
-    bool bias_in_kernel = false;
+    bool bias_in_kernel = false, patch_folded = false;
     if (!force_v1 && wgrad2_eligible(P)) {  // ... or v2 for the vector members
         int bm, bn;
         tile_dims(tile, bm, bn);
@@ -958,8 +958,10 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
                 P.dbias = direct ? dbias : bias_part;
                 bias_in_kernel = true;
             }
-            if (!direct && wgrad_patch_eligible(P)) {
+            // (flat members on the v1 tiles would write phase-form columns into the same slabs)
+            if (!direct && wgrad_patch_eligible(P) && (flat_valu || nflat == 0)) {
                 conv_note_patch(2);
+                patch_folded = true;    // its slabs are [S][Cout][3][3][Cin_tot] already
                 rc = wgrad_patch_launch(P, st);
             } else {
                 rc = wgrad2_launch(P, tile, nt, st);
@@ -1004,7 +1006,13 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
     const bool bias_tail_needed = bias_in_kernel && !direct;
     const int nb_bias = bias_tail_needed ? (P.Cout + 255) / 256 : 0;
     if (!direct && (any_vec || !flat_valu)) {
-        if (P.nph == 4) {
+        if (patch_folded) {
+            const size_t w9 = (size_t)P.Cout * 9 * P.Cin_tot;
+            const int nbm = (int)((w9 + 1023) / 1024);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(nbm + nb_bias)), dim3(256), 0, st,
+                               (const float *)ws, dW, w9, S, nbm, (const float *)bias_part, nslab,
+                               P.Cout, dbias);
+        } else if (P.nph == 4) {
             const size_t n = (size_t)P.Cout * 9 * ((P.Cin_tot + 3) / 4);
             const int zg = S <= 2 ? 1 : S <= 8 ? 4 : 16;
             const int nbm = (int)((n + 256 / zg - 1) / (256 / zg));

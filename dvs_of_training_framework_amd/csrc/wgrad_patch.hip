@@ -62,6 +62,47 @@ __device__ __forceinline__ int wp_swz(int n)
     return CT == 64 ? (n >> 1) & 1 : 0;
 }
 
+// Epilogue of both kernels: the 16 (phase, tap) tiles of the workgroup FOLDED to the 9 taps of
+// the 3x3 gradient before they leave it (subpixel_fold_kernel's rule: per axis kernel row
+// k = 0 <- (phase 0, tap 0) + (phase 1, tap 0); 1 <- (0, 1) + (1, 0); 2 <- (0, 1) + (1, 1)).
+// The phases are waves, so the tiles meet in LDS (64 KiB: the ring, no longer in use), in the
+// accumulator layout [tile][register][lane] -- a lane adds ITS element of four tiles, in a
+// fixed order.  Slabs are [split][Cout][3][3][Cin_tot]: 9/16 of the phase-form bytes, written
+// once and read once by the plain slab reduce.
+template <int NB>
+__device__ __forceinline__ void wp_fold_store(const WGradParams &P, f32x16 (&acc)[4][NB], unsigned char *smem,
+                                              int wave, int lane, int split, int co0, int col0)
+{
+    float *xs = (float *)smem;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const size_t row9 = (size_t)9 * P.Cin_tot;
+    float *dW = P.dW + (size_t)split * P.Cout * row9;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        __builtin_amdgcn_s_barrier();       // last stage read / previous pass folded
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) xs[((wave * 4 + t) * 16 + reg) * 64 + lane] = acc[t][nb][reg];
+        __builtin_amdgcn_s_barrier();
+        for (int k = wave; k < 9; k += 4) {
+            const int ky = k / 3, kx = k - 3 * ky;
+            // contributors (phase bit, tap bit) per axis: (0, k > 0) and (1, k == 2)
+            const int ty0 = ky > 0, ty1 = ky == 2, tx0 = kx > 0, tx1 = kx == 2;
+            const float *s00 = xs + ((0 * 4 + 2 * ty0 + tx0) * 16) * 64 + lane;     // phase (0,0)
+            const float *s01 = xs + ((1 * 4 + 2 * ty0 + tx1) * 16) * 64 + lane;     // phase (0,1)
+            const float *s10 = xs + ((2 * 4 + 2 * ty1 + tx0) * 16) * 64 + lane;     // phase (1,0)
+            const float *s11 = xs + ((3 * 4 + 2 * ty1 + tx1) * 16) * 64 + lane;     // phase (1,1)
+            const size_t col = (size_t)k * P.Cin_tot + col0 + 32 * nb + lrow;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                dW[(size_t)co * row9 + col] = ((s00[reg * 64] + s01[reg * 64]) + s10[reg * 64]) + s11[reg * 64];
+            }
+        }
+    }
+}
+
 template <int CT>
 __global__ __launch_bounds__(CONV_NT) void wgrad_patch_twins_kernel(const WGradParams P)
 {
@@ -239,19 +280,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_patch_twins_kernel(const WGradP
         const float v = bsum + __shfl_xor(bsum, 32);
         if (lh == 0) P.dbias[(size_t)slab * P.Cout + co0 + lrow] = v;
     }
-    const size_t wsize = (size_t)P.Cout * 4 * P.Cin_tot;
-    float *dW = P.dW + (size_t)slab * wsize;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int nb = 0; nb < G::NB; ++nb) {
-            const size_t col = (size_t)t * P.Cin_tot + coff + c0 + 32 * nb + lrow;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                dW[(size_t)co * 4 * P.Cin_tot + col] = acc[t][nb][reg];
-            }
-        }
+    wp_fold_store<G::NB>(P, acc, smem, wave, lane, split, co0, coff + c0);
 #endif
 }
 
@@ -455,19 +484,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_patch_f32_kernel(const WGradPar
         const float v = bsum + __shfl_xor(bsum, 32);
         if (lh == 0) P.dbias[(size_t)slab * P.Cout + co0 + lrow] = v;
     }
-    const size_t wsize = (size_t)P.Cout * 4 * P.Cin_tot;
-    float *dW = P.dW + (size_t)slab * wsize;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int nb = 0; nb < G::NB; ++nb) {
-            const size_t col = (size_t)t * P.Cin_tot + coff + c0 + 32 * nb + lrow;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                dW[(size_t)co * 4 * P.Cin_tot + col] = acc[t][nb][reg];
-            }
-        }
+    wp_fold_store<G::NB>(P, acc, smem, wave, lane, split, co0, coff + c0);
 #endif
 }
 
@@ -582,7 +599,8 @@ static int wp_launch(WGradParams &P, hipStream_t st)
         if (!P.src[s].flat) nt += P.src[s].C / CT;
     }
     P.tile_begin[P.nsrc] = nt;
-    constexpr size_t LDS = (size_t)WPGeom<CT>::NS * WPGeom<CT>::STAGE;
+    constexpr size_t LDS0 = (size_t)WPGeom<CT>::NS * WPGeom<CT>::STAGE;
+    constexpr size_t LDS = LDS0 < 65536 ? 65536 : LDS0;     // the fold of the epilogue: 16 tiles of 4 KiB
     static bool attr_set = false;
     if (!attr_set) {
         DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_patch_twins_kernel<CT>,
@@ -606,7 +624,8 @@ static int wp_launch_f32(WGradParams &P, hipStream_t st)
         if (!P.src[s].flat) nt += P.src[s].C / CT;
     }
     P.tile_begin[P.nsrc] = nt;
-    constexpr size_t LDS = (size_t)WPGeomF<CT>::NS * WPGeomF<CT>::STAGE;
+    constexpr size_t LDS0 = (size_t)WPGeomF<CT>::NS * WPGeomF<CT>::STAGE;
+    constexpr size_t LDS = LDS0 < 65536 ? 65536 : LDS0;     // the fold of the epilogue: 16 tiles of 4 KiB
     static bool attr_set = false;
     if (!attr_set) {
         DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)wgrad_patch_f32_kernel<CT>,
