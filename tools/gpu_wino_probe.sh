@@ -8,5 +8,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for dbg in ${DBGS:-0 64 320 65 66 68 72 80 96 192}; do
   DVSOF_PROBE_LIB=1 DVSOF_GCONV_DBG=$dbg timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${S}_wp_$dbg -o p -- python3 $R/tools/wino_probe.py $B $K > $O/${S}_wp_$dbg.log 2>&1 || { echo "dbg $dbg failed"; tail -5 $O/${S}_wp_$dbg.log; exit 1; }
-  echo "dbg=$dbg $(grep -E 'gconv2_kernel|wgrad2_kernel' $O/${S}_wp_$dbg/p_kernel_stats.csv | awk -F'","' '{printf "%s calls %s avg_ns %s | ", substr($1,1,60), $2, $4}')"
+  python3 - $dbg $O/${S}_wp_$dbg/p_kernel_stats.csv <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[2])):
+    if 'gconv2_kernel' in r['Name'] or 'wgrad2_kernel' in r['Name']:
+        print(f"dbg={sys.argv[1]} {r['Name'][5:48]} calls {r['Calls']} avg_us {float(r['AverageNs']) / 1e3:.1f}")
+PY
+  rm -rf $O/${S}_wp_$dbg
 done
