@@ -81,13 +81,15 @@ def parse():
                    help='conv matrix-core operand type (bf16: f32 storage and '
                         'accumulation, operands rounded in registers; bf16s: bf16 twins of '
                         'activations / gradients / prepared weights streamed through LDS)')
-    p.add_argument('--fused-optimizer', nargs='?', const='coarse', default=None,
-                   choices=('coarse', 'buckets'),
+    p.add_argument('--fused-optimizer', nargs='?', const='buckets', default='auto',
+                   choices=('auto', 'none', 'coarse', 'buckets'),
                    help='update parameters during the backward (optim.fuse_into_backward) '
-                        'instead of in optimizer.step(): "coarse" = decoder + residual '
-                        'parameters in one launch when their last weight gradient is done '
-                        '(beside the encoder backward), "buckets" = one launch per gradient '
-                        'bucket')
+                        'instead of in optimizer.step(): "buckets" = one launch per gradient '
+                        'bucket as soon as its gradients are final (behind its all-reduce '
+                        'under data parallelism), "coarse" = decoder + residual parameters in '
+                        'one launch when their last weight gradient is done; auto (as '
+                        'train_flownet.py --optimizer-in-backward auto): buckets for f32 on '
+                        'one GPU, none for the bf16 modes and under data parallelism')
     p.add_argument('--graph', action='store_true',
                    help='replay the step as ONE hipGraph launch (capture.CapturedTrainStep; '
                         'single GPU, bit-identical results)')
@@ -121,9 +123,15 @@ class Harness:
         self.model.train()
         self.opt = FusedAdamW(self.model.predictor.parameters(), lr=1e-3,
                               weight_decay=1e-4, amsgrad=True)
-        if getattr(a, 'fused_optimizer', False):
+        fo = getattr(a, 'fused_optimizer', 'auto')
+        if fo == 'auto':    # measured: +1.5 % in f32 on one GPU; behind the exchange marks of a
+            # (1-rank) group the per-bucket waits cost more than the overlap gives (-6 %)
+            alone = int(os.environ.get('WORLD_SIZE', '1')) == 1 and os.environ.get('DVSOF_FORCE_DIST') != '1'
+            fo = 'buckets' if getattr(a, 'dtype', 'f32') == 'f32' and alone else 'none'
+        if fo != 'none':
             self.opt.fuse_into_backward(self.model.predictor,
-                                        flush_at=None if a.fused_optimizer == 'buckets' else (5,))
+                                        flush_at=None if fo == 'buckets' else (5,))
+        self.fused_optimizer = fo
         self.sched = torch.optim.lr_scheduler.LambdaLR(
             self.opt, lambda s: 2 ** (-s / 100000))
         self.losses = init_losses((a.height, a.width), a.batch, self.model,
@@ -553,6 +561,8 @@ def train_loop_rates(a, device, steps=120, warm=30):
         torch.manual_seed(1234)
         model = Model(device, event_representation_depth=a.bins, compute_dtype=a.dtype)
         opt = FusedAdamW(model.predictor.parameters(), lr=1e-3, weight_decay=1e-4, amsgrad=True)
+        if capture and a.dtype == 'f32' and getattr(a, 'fused_optimizer', 'auto') in ('auto', 'buckets'):
+            opt.fuse_into_backward(model.predictor)     # train_flownet.py --optimizer-in-backward auto
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 2 ** (-s / 100000))
         ev = init_losses((a.height, a.width), a.batch, model, device, sequence_length=1)
         host = [pin(b) for b in pool] if feeder else pool
@@ -662,6 +672,8 @@ def main():
             f'step executor: {ex.kernels} kernels on {ex.lanes} streams {ex.lane_kernels}, '
             f'{ex.events} events / {ex.waits} waits per step, one C call'
             + f', lane plan "{ex.plan()[0]}"'
+            + ('' if h.fused_optimizer == 'none' else
+               f', AdamW per gradient bucket inside the backward ({h.fused_optimizer})')
             + (f'; {ex.marks} exchange marks (bucket all-reduces issued by the executor on the '
                'exchange stream)' if ex.marks else ''))
     if not a.no_roofline:
@@ -714,7 +726,14 @@ def main():
                 h.reducer.close()
         except Exception as e:      # noqa: BLE001 -- shutting down
             print(f'reducer.close: {e}', file=sys.stderr)
-        torch.distributed.destroy_process_group()
+        # The line is out and every rank is past the barrier.  torch's ProcessGroupNCCL
+        # teardown (destroy_process_group / interpreter exit with a live group) aborts now
+        # and then on this ROCm build (SIGABRT from a watchdog thread, seen in 1 of ~30
+        # 1-rank runs): leave without running it.
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

@@ -216,8 +216,9 @@ class CapturedTrainStep:
         assert hasattr(optimizer, 'begin_capture'), \
             'the captured step needs optim.FusedAdamW (device-resident lr table)'
         assert role in ROLES and (role == 'full') == (accumulation_steps == 1)
-        assert not getattr(optimizer, 'fused_active', False), \
-            'optim.fuse_into_backward and the captured step exclude each other'
+        # (optim.fuse_into_backward: the bucket updates are kernels of the capture like any
+        # other; under data parallelism each follows its bucket's exchange mark and the
+        # executor makes it wait for that collective)
         self.model, self.evaluator, self.optimizer = model, evaluator, optimizer
         self.weights, self.device = list(weights), torch.device(device)
         self.reducer, self.role, self.accum = reducer, role, int(accumulation_steps)

@@ -60,6 +60,9 @@ struct XNode {
     float *mark_ptr = nullptr;
     size_t mark_n = 0;
     hipEvent_t mark_ev = nullptr;   // BUCKET: the lane's progress the exchange stream waits for
+    hipEvent_t xdone_ev = nullptr;  // BUCKET: the exchange stream's progress behind this collective
+    std::vector<int> xwait;         // BUCKET marks this kernel follows directly: it waits for their
+                                    // collectives (a bucket's optimizer update inside the backward)
     int lane;
     int id = 0;              // position in capture (topological) order: what plans are written in
     int lane0 = 0;           // lane of the greedy chain split made at creation
@@ -110,14 +113,17 @@ int wire(Exec *x)
         if (n.ev) (void)hipEventDestroy(n.ev);
         n.ev = nullptr;
         n.wait.clear();
+        n.xwait.clear();
     }
     x->n_events = x->n_waits = 0;
     std::vector<std::vector<int>> seen(L, std::vector<int>(L, -1));
     for (int i = 0; i < nn; ++i) {
         XNode &n = x->nodes[i];
         std::vector<int> w;
-        for (int d : n.deps)
+        for (int d : n.deps) {
             if (x->nodes[d].lane != n.lane) w.push_back(d);
+            if (!n.mark && x->nodes[d].mark == DVSOF_MARK_BUCKET) n.xwait.push_back(d);
+        }
         std::sort(w.begin(), w.end(), [](int a, int b) { return a > b; });
         for (int d : w) {
             const int pl = x->nodes[d].lane;
@@ -302,6 +308,7 @@ void destroy(Exec *x)
     for (auto &n : x->nodes) {
         if (n.ev) (void)hipEventDestroy(n.ev);
         if (n.mark_ev) (void)hipEventDestroy(n.mark_ev);
+        if (n.xdone_ev) (void)hipEventDestroy(n.xdone_ev);
     }
     if (x->xdone) (void)hipEventDestroy(x->xdone);
     if (x->t0) (void)hipEventDestroy(x->t0);
@@ -336,7 +343,10 @@ int run_mark(Exec *x, XNode &n, hipStream_t st)
             DVSOF_HIP_TRY(hipEventRecord(n.mark_ev, st));
             DVSOF_HIP_TRY(hipStreamWaitEvent(xs, n.mark_ev, 0));
         }
-        return dvsof_allreduce_bucket(x->comm, n.mark_ptr, n.mark_n, (void *)xs);
+        const int rc = dvsof_allreduce_bucket(x->comm, n.mark_ptr, n.mark_n, (void *)xs);
+        if (rc) return rc;
+        if (xs != st) DVSOF_HIP_TRY(hipEventRecord(n.xdone_ev, xs));
+        return DVSOF_OK;
     }
     if (n.mark == DVSOF_MARK_JOIN && xs != st) {
         DVSOF_HIP_TRY(hipEventRecord(x->xdone, xs));
@@ -366,8 +376,10 @@ int dvsof_exec_set_comm(void *exec, void *comm, void *exchange_stream)
     x->xstream = as_stream(exchange_stream);
     if (comm && !x->xdone) DVSOF_HIP_TRY(hipEventCreateWithFlags(&x->xdone, hipEventDisableTiming));
     for (auto &n : x->nodes)
-        if (comm && n.mark == DVSOF_MARK_BUCKET && !n.mark_ev)
+        if (comm && n.mark == DVSOF_MARK_BUCKET && !n.mark_ev) {
             DVSOF_HIP_TRY(hipEventCreateWithFlags(&n.mark_ev, hipEventDisableTiming));
+            DVSOF_HIP_TRY(hipEventCreateWithFlags(&n.xdone_ev, hipEventDisableTiming));
+        }
     return DVSOF_OK;
 }
 
@@ -660,6 +672,8 @@ int dvsof_exec_launch(void *exec, void *stream)
             const int rc_ = run_mark(x, n, st);
             if (rc_) return rc_;
         } else if (n.kernel) {
+            if (x->comm && x->xstream && x->xstream != st)
+                for (int d : n.xwait) DVSOF_HIP_TRY(hipStreamWaitEvent(st, x->nodes[d].xdone_ev, 0));
             const int rc_ = launch_node(n, st);
             if (rc_) return rc_;
         }

@@ -180,13 +180,16 @@ class GradReducer:
         if flat.is_cuda and torch.cuda.is_current_stream_capturing():
             # a captured step (capture.py): leave a MARK where the collective
             # goes; the step executor issues it on every replay (csrc/exec.hip)
-            assert after is None, \
-                'the optimizer fused into the bucket hooks is not captured'
             from . import _lib
             _lib.check(_lib.lib().dvsof_exec_mark(
                 1, self._marked, flat.data_ptr(), flat.numel(), _lib.stream()),
                 'dvsof_exec_mark')
             self._marked += 1
+            if after is not None:
+                # optim.fuse_into_backward: this bucket's update, captured right behind
+                # its mark -- the executor makes a kernel that follows a BUCKET mark wait
+                # for that mark's collective
+                after()
             return
         self.bytes_reduced += flat.numel() * flat.element_size()
         if flat.is_cuda and self._comm is not None and self._direct:

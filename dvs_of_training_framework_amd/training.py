@@ -268,8 +268,7 @@ def train(model, device, loader, optimizer, num_steps: int, scheduler, logger,
                        init_samples_passed)
     sums = ScaleSums()
     captured = None
-    if capture and is_raw and hasattr(optimizer, 'begin_capture') and \
-            not hasattr(optimizer, 'fused_active'):
+    if capture and is_raw and hasattr(optimizer, 'begin_capture'):
         from .capture import CapturedLoop
         captured = CapturedLoop(model, evaluator, optimizer, weights, device,
                                 accumulation_steps, reducer)

@@ -646,6 +646,9 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
  *   DVSOF_MARK_BUCKET  (bucket, n): the exchange stream waits for the lane's
  *                      progress, then dvsof_allreduce_bucket(comm, bucket, n)
  *                      on the exchange stream
+ *                      A KERNEL captured directly behind a BUCKET mark (the
+ *                      update of that bucket's parameters, when the optimizer
+ *                      runs inside the backward) waits for that collective
  *   DVSOF_MARK_JOIN    the lane waits for the exchange stream (in front of
  *                      the optimizer kernels)
  *   dvsof_exec_set_comm  communicator (dvsof_comm_create) and exchange stream

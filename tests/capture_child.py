@@ -241,6 +241,11 @@ def scenario_big(dtype):
     from dvs_of_training_framework_amd.training import process_minibatch
     import time
     B, H, W, steps = 8, 256, 256, 4
+    # "<dtype>:fused": the replayed leg updates every gradient bucket inside the backward
+    # (optim.fuse_into_backward; behind the bucket's exchange mark under the reducer), the
+    # eager leg in optimizer.step() -- same arithmetic, so still bit-identical
+    fused = dtype.endswith(':fused')
+    dtype = dtype.split(':')[0]
     red = _dist()
     batches = [synthetic.to_torch(synthetic.make_batch(900 + i, B, H, W, None), 'cuda')
                for i in range(2)]
@@ -269,6 +274,8 @@ def scenario_big(dtype):
     def replayed():
         model, opt, sched, init_losses = make(dtype=dtype)
         model.predictor.reducer = red
+        if fused:
+            opt.fuse_into_backward(model.predictor)
         ev = init_losses((H, W), B, model, 'cuda', sequence_length=1)
         caps, losses = {}, []
         host = 0.0
@@ -458,13 +465,17 @@ def scenario_audit():
 
 
 def _shutdown():
-    """Orderly end of a 1-rank group: the C ABI's communicator, then the process group (an
-    exit with live communicators races RCCL's threads against the interpreter's teardown:
-    seen once as an abort after the result line had been printed)."""
+    """End of a child that joined a 1-rank group: the result line is out; torch's
+    ProcessGroupNCCL teardown (destroy_process_group as well as an interpreter exit with a
+    live group) aborts now and then on this ROCm build -- SIGABRT from a watchdog thread
+    after the result had been printed, 1 run in ~30 -- so the process leaves without it."""
+    import os
     import torch.distributed as dist
     if dist.is_initialized():
         torch.cuda.synchronize()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

@@ -103,6 +103,20 @@ def test_executor_issues_the_gradient_exchange_under_data_parallelism(dtype):
     assert x['host_ms_per_step'] <= 0.8, x
 
 
+@pytest.mark.parametrize('dist', [False, True])
+def test_executor_with_the_optimizer_inside_the_backward(dist):
+    """optim.fuse_into_backward under the captured step: every gradient bucket
+    is updated as soon as its gradients are final -- a kernel of the capture
+    like any other; inside a (1-rank) RCCL group each update follows its
+    bucket's exchange mark and the executor makes it wait for that collective.
+    The eager leg updates in optimizer.step(): same arithmetic, bit-identical
+    losses and weights at the benchmark shape."""
+    r = run('big:f32:fused', dist=dist)
+    assert r['dist'] == dist and r['losses_equal'] and r['weights_equal'], r
+    x = r['executor']
+    assert x['kernels'] >= 120 and x['marks'] == (9 if dist else 0), x
+
+
 @pytest.mark.parametrize('dp', [False, True])
 def test_train_loop_captures_gradient_accumulation(dp):
     """train(accumulation_steps=3, capture=True): the roles first / middle /

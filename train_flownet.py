@@ -204,6 +204,12 @@ def main(argv=None):
                 'no dataset pipeline importable (the reference\'s utils.* and '
                 f'h5py are needed: {e}); pass --synthetic') from e
 
+    oib = getattr(args, 'optimizer_in_backward', 'auto')
+    if device.type == 'cuda' and hasattr(optimizer, 'fuse_into_backward') and \
+            hasattr(model, 'predictor') and \
+            (oib == 'on' or (oib == 'auto' and reducer is None and
+                             getattr(args, 'compute_dtype', 'f32') == 'f32')):
+        optimizer.fuse_into_backward(model.predictor)
     if getattr(args, 'device_feeder', False) and device.type == 'cuda' and args.is_raw:
         from dvs_of_training_framework_amd.feed import DeviceFeeder
         loader = DeviceFeeder(loader, device)
