@@ -21,9 +21,16 @@ def main():
     for r in rows:
         r['s'], r['e'] = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     rows.sort(key=lambda r: r['s'])
-    ad = [i for i, r in enumerate(rows) if 'adamw' in r['Kernel_Name'] or 'radam' in r['Kernel_Name']]
-    k = int(args[0]) if args else len(ad) // 2
-    a, b = ad[k], ad[k + 1]
+    # a captured step begins with set_dynamic_kernel (the optimizer's per-step table); without
+    # it steps are cut at the optimizer kernel (one per step unless the update runs per bucket)
+    sd = [i for i, r in enumerate(rows) if 'set_dynamic_kernel' in r['Kernel_Name']]
+    if len(sd) >= 3:
+        k = int(args[0]) if args else max(0, len(sd) - 3)     # a late step: past the executor's plan trials
+        a, b = sd[k] - 1, sd[k + 1] - 1
+    else:
+        ad = [i for i, r in enumerate(rows) if 'adamw' in r['Kernel_Name'] or 'radam' in r['Kernel_Name']]
+        k = int(args[0]) if args else len(ad) // 2
+        a, b = ad[k], ad[k + 1]
     t0 = rows[a]['e']
     step = rows[a + 1:b + 1]
     print(f'step {k}: {(rows[b]["e"] - t0) / 1e3:.1f} us, {len(step)} kernels')
