@@ -726,14 +726,8 @@ def main():
                 h.reducer.close()
         except Exception as e:      # noqa: BLE001 -- shutting down
             print(f'reducer.close: {e}', file=sys.stderr)
-        # The line is out and every rank is past the barrier.  torch's ProcessGroupNCCL
-        # teardown (destroy_process_group / interpreter exit with a live group) aborts now
-        # and then on this ROCm build (SIGABRT from a watchdog thread, seen in 1 of ~30
-        # 1-rank runs): leave without running it.
         torch.cuda.synchronize()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -333,7 +333,12 @@ class CapturedTrainStep:
         optimizer.begin_capture(dev)
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if executor \
             else torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a process group's watchdog thread polls its work events with
+        # hipEventQuery whenever it likes; under the default (global) capture mode such a call
+        # from ANOTHER thread invalidates this capture and kills the watchdog ("operation not
+        # permitted when stream is capturing" -> SIGABRT, seen in 1 of 3..30 runs of a 1-rank
+        # group).  Everything the step itself enqueues comes from this thread.
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             loss, terms, _ = self._body(self.static, FakeTimer())
         self.loss = loss.detach()
         self._terms = terms._terms      # _Terms: .packed is the [3,K] tensor

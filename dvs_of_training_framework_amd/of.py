@@ -86,7 +86,7 @@ class OpticalFlow:
             self._net.strict = False
             torch.cuda.synchronize(self._device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):   # see capture.py
                 g['flow'] = self._net(g['ev'], g['ts'], g['sidx'], self.imsize,
                                       batch_size=B)[0]
             g['graph'] = graph

@@ -465,17 +465,14 @@ def scenario_audit():
 
 
 def _shutdown():
-    """End of a child that joined a 1-rank group: the result line is out; torch's
-    ProcessGroupNCCL teardown (destroy_process_group as well as an interpreter exit with a
-    live group) aborts now and then on this ROCm build -- SIGABRT from a watchdog thread
-    after the result had been printed, 1 run in ~30 -- so the process leaves without it."""
-    import os
+    """Orderly end of a child that joined a 1-rank group.  (The aborts these children showed
+    now and then -- SIGABRT, "operation not permitted when stream is capturing" from the
+    process group's watchdog thread -- came from stream capture in the default GLOBAL error
+    mode: capture.py records in thread_local mode now.)"""
     import torch.distributed as dist
     if dist.is_initialized():
         torch.cuda.synchronize()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

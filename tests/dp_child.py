@@ -82,12 +82,8 @@ def main():
         'direct_bit_identical': same(g_plain, g_dir) and same(w_plain, w_dir) and
         same(w_plain, w_dir_fused),
         'direct_bytes': direct_bytes}), flush=True)
-    # (no destroy_process_group: torch's ProcessGroupNCCL teardown aborts now and then on
-    # this ROCm build after the result is out -- see tests/capture_child.py:_shutdown)
     torch.cuda.synchronize()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    dist.destroy_process_group()
 
 
 if __name__ == '__main__':
