@@ -61,8 +61,8 @@ struct XNode {
     size_t mark_n = 0;
     hipEvent_t mark_ev = nullptr;   // BUCKET: the lane's progress the exchange stream waits for
     hipEvent_t xdone_ev = nullptr;  // BUCKET: the exchange stream's progress behind this collective
-    std::vector<int> xwait;         // BUCKET marks this kernel follows directly: it waits for their
-                                    // collectives (a bucket's optimizer update inside the backward)
+    bool xdone_used = false;        // a WAIT mark refers to this BUCKET mark (else xdone_ev is not recorded)
+    int wait_for = -1;              // WAIT: position of the BUCKET mark whose collective the lane waits for
     int lane;
     int id = 0;              // position in capture (topological) order: what plans are written in
     int lane0 = 0;           // lane of the greedy chain split made at creation
@@ -113,17 +113,25 @@ int wire(Exec *x)
         if (n.ev) (void)hipEventDestroy(n.ev);
         n.ev = nullptr;
         n.wait.clear();
-        n.xwait.clear();
+        n.xdone_used = false;
+        n.wait_for = -1;
+    }
+    for (int i = 0; i < nn; ++i) {      // WAIT marks find their BUCKET mark (same mark index)
+        XNode &n = x->nodes[i];
+        if (n.mark != DVSOF_MARK_WAIT) continue;
+        for (int j = 0; j < nn; ++j)
+            if (x->nodes[j].mark == DVSOF_MARK_BUCKET && x->nodes[j].mark_index == n.mark_index) {
+                n.wait_for = j;
+                x->nodes[j].xdone_used = true;
+            }
     }
     x->n_events = x->n_waits = 0;
     std::vector<std::vector<int>> seen(L, std::vector<int>(L, -1));
     for (int i = 0; i < nn; ++i) {
         XNode &n = x->nodes[i];
         std::vector<int> w;
-        for (int d : n.deps) {
+        for (int d : n.deps)
             if (x->nodes[d].lane != n.lane) w.push_back(d);
-            if (!n.mark && x->nodes[d].mark == DVSOF_MARK_BUCKET) n.xwait.push_back(d);
-        }
         std::sort(w.begin(), w.end(), [](int a, int b) { return a > b; });
         for (int d : w) {
             const int pl = x->nodes[d].lane;
@@ -345,7 +353,11 @@ int run_mark(Exec *x, XNode &n, hipStream_t st)
         }
         const int rc = dvsof_allreduce_bucket(x->comm, n.mark_ptr, n.mark_n, (void *)xs);
         if (rc) return rc;
-        if (xs != st) DVSOF_HIP_TRY(hipEventRecord(n.xdone_ev, xs));
+        if (xs != st && n.xdone_used) DVSOF_HIP_TRY(hipEventRecord(n.xdone_ev, xs));
+        return DVSOF_OK;
+    }
+    if (n.mark == DVSOF_MARK_WAIT) {
+        if (xs != st && n.wait_for >= 0) DVSOF_HIP_TRY(hipStreamWaitEvent(st, x->nodes[n.wait_for].xdone_ev, 0));
         return DVSOF_OK;
     }
     if (n.mark == DVSOF_MARK_JOIN && xs != st) {
@@ -361,7 +373,7 @@ extern "C" {
 
 int dvsof_exec_mark(int kind, int index, float *bucket, size_t n, void *stream)
 {
-    if (kind != DVSOF_MARK_BUCKET && kind != DVSOF_MARK_JOIN) return DVSOF_EINVAL;
+    if (kind != DVSOF_MARK_BUCKET && kind != DVSOF_MARK_JOIN && kind != DVSOF_MARK_WAIT) return DVSOF_EINVAL;
     if (kind == DVSOF_MARK_BUCKET && (!bucket || n == 0)) return DVSOF_EINVAL;
     hipLaunchKernelGGL(exec_mark_kernel, dim3(1), dim3(1), 0, as_stream(stream), kind, index, bucket, n);
     DVSOF_LAUNCH_CHECK();
@@ -512,6 +524,28 @@ int dvsof_exec_create(void *graph_, void *const *side_streams, int n_side, void 
         n.id = (int)i;
         tail[lane] = (int)i;
         n.deps = n.deps_id = deps;
+    }
+    // A BUCKET mark is a side effect of its stream, not a producer: what follows it in the
+    // capture follows what PRECEDED it.  Kernels inherit the mark's dependencies instead of
+    // depending on the mark (else the kernel behind a mark is tied to the mark's lane and, in
+    // another lane, pays a cross-lane wait per bucket); the other marks keep theirs (the JOIN
+    // has to be issued behind every collective, a WAIT behind its own).
+    for (size_t i = 0; i < nn; ++i) {
+        XNode &n = x->nodes[i];
+        if (n.mark) continue;
+        std::vector<int> out;
+        std::vector<int> todo(n.deps_id.begin(), n.deps_id.end());
+        while (!todo.empty()) {
+            const int d = todo.back();
+            todo.pop_back();
+            if (x->nodes[d].mark == DVSOF_MARK_BUCKET) {
+                for (int dd : x->nodes[d].deps_id) todo.push_back(dd);
+            } else if (std::find(out.begin(), out.end(), d) == out.end()) {
+                out.push_back(d);
+            }
+        }
+        std::sort(out.begin(), out.end());
+        n.deps = n.deps_id = out;
     }
     for (int l = 0; l < n_side; ++l) x->side.push_back((hipStream_t)side_streams[l]);
     {
@@ -672,8 +706,6 @@ int dvsof_exec_launch(void *exec, void *stream)
             const int rc_ = run_mark(x, n, st);
             if (rc_) return rc_;
         } else if (n.kernel) {
-            if (x->comm && x->xstream && x->xstream != st)
-                for (int d : n.xwait) DVSOF_HIP_TRY(hipStreamWaitEvent(st, x->nodes[d].xdone_ev, 0));
             const int rc_ = launch_node(n, st);
             if (rc_) return rc_;
         }

@@ -184,12 +184,16 @@ class GradReducer:
             _lib.check(_lib.lib().dvsof_exec_mark(
                 1, self._marked, flat.data_ptr(), flat.numel(), _lib.stream()),
                 'dvsof_exec_mark')
-            self._marked += 1
             if after is not None:
-                # optim.fuse_into_backward: this bucket's update, captured right behind
-                # its mark -- the executor makes a kernel that follows a BUCKET mark wait
-                # for that mark's collective
+                # optim.fuse_into_backward: this bucket's update behind a WAIT mark -- the
+                # executor makes the lane wait for THIS bucket's collective there
+                _lib.check(_lib.lib().dvsof_exec_mark(
+                    3, self._marked, flat.data_ptr(), flat.numel(), _lib.stream()),
+                    'dvsof_exec_mark')
+                self._marked += 1
                 after()
+                return
+            self._marked += 1
             return
         self.bytes_reduced += flat.numel() * flat.element_size()
         if flat.is_cuda and self._comm is not None and self._direct:

@@ -646,9 +646,11 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
  *   DVSOF_MARK_BUCKET  (bucket, n): the exchange stream waits for the lane's
  *                      progress, then dvsof_allreduce_bucket(comm, bucket, n)
  *                      on the exchange stream
- *                      A KERNEL captured directly behind a BUCKET mark (the
- *                      update of that bucket's parameters, when the optimizer
- *                      runs inside the backward) waits for that collective
+ *                      Kernels captured behind a BUCKET mark do NOT depend on
+ *                      it: they inherit what preceded the mark
+ *   DVSOF_MARK_WAIT    (index of a BUCKET mark): the lane waits for THAT
+ *                      collective (in front of the update of that bucket's
+ *                      parameters when the optimizer runs inside the backward)
  *   DVSOF_MARK_JOIN    the lane waits for the exchange stream (in front of
  *                      the optimizer kernels)
  *   dvsof_exec_set_comm  communicator (dvsof_comm_create) and exchange stream
@@ -663,6 +665,7 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
  * ------------------------------------------------------------------ */
 #define DVSOF_MARK_BUCKET 1
 #define DVSOF_MARK_JOIN 2
+#define DVSOF_MARK_WAIT 3
 int dvsof_exec_mark(int kind, int index, float *bucket, size_t n, void *stream);
 int dvsof_exec_set_comm(void *exec, void *comm, void *exchange_stream);
 int dvsof_exec_marks(void *exec, int *n_marks);
