@@ -12,6 +12,12 @@ HBM before the timed region starts.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Both forms work for N > 1: started WITHOUT a launcher (no RANK / WORLD_SIZE
+in the environment) the process only parses its arguments and starts its own N
+ranks as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+127.0.0.1 rendezvous) BEFORE anything touches the GPU, forwards rank 0's one
+JSON line and returns non-zero if any rank fails (`self_launch`).
+
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
 `roofline` (dominant conv kernel: FLOPs the matrix cores execute / HIP-event
 time on the launch stream / dense peak, so `frac` <= 1; the algorithmic
@@ -29,10 +35,91 @@ from pathlib import Path
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see dvs_of_training_framework_amd/__init__.py
 os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
 
-import torch  # noqa: E402
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start
+    the N ranks ourselves.  This process never imports torch and never touches
+    the GPU (no exec of a GPU-initialised process either): it spawns N children
+    of this same script with the torchrun environment, forwards rank 0's stdout
+    (the JSON line) to its own, every other rank's stdout and all stderr to its
+    stderr, and waits.  The first rank that exits non-zero ends the run: the
+    others are terminated (they would wait for it in a collective) and its exit
+    code is returned.  -> exit code, or None when this process is a rank
+    itself (or N = 1)."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    n = 1
+    for i, tok in enumerate(argv):
+        if tok == '--gpus' and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif tok.startswith('--gpus='):
+            n = int(tok.split('=', 1)[1])
+    if n <= 1 or 'RANK' in os.environ or 'WORLD_SIZE' in os.environ:
+        return None
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    kids = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        kids.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv),
+                                     env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True))
+
+    def pump(r, k):
+        for line in k.stdout:
+            if r == 0:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(f'[rank {r}] {line}')
+    pumps = [threading.Thread(target=pump, args=(r, k), daemon=True) for r, k in enumerate(kids)]
+    for t in pumps:
+        t.start()
+    deadline = time.time() + float(os.environ.get('DVSOF_LAUNCH_TIMEOUT', '3000'))
+    rc, why = 0, None
+    while any(k.poll() is None for k in kids):
+        bad = [(r, k.returncode) for r, k in enumerate(kids) if k.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = bad[0][1] if bad else 124
+            why = (f'rank {bad[0][0]} exited with code {bad[0][1]}' if bad
+                   else 'DVSOF_LAUNCH_TIMEOUT reached')
+            for k in kids:          # exactly the processes started above
+                if k.poll() is None:
+                    k.send_signal(signal.SIGTERM)
+            t_end = time.time() + 10
+            while any(k.poll() is None for k in kids) and time.time() < t_end:
+                time.sleep(0.1)
+            for k in kids:
+                if k.poll() is None:
+                    k.kill()
+            break
+        time.sleep(0.05)
+    for k in kids:
+        k.wait()
+    for t in pumps:
+        t.join(2)
+    if not rc:
+        rc = next((k.returncode for k in kids if k.returncode), 0)
+        if rc:
+            why = f'a rank exited with code {rc}'
+    if rc:
+        print(f'bench.py: {n}-rank run failed: {why}; the other ranks were stopped', file=sys.stderr)
+    return rc if rc >= 0 else 128 - rc      # killed by a signal: the shell convention
+
+
+if __name__ == '__main__':
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
+import torch  # noqa: E402
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_BF16_MATRIX_TFLOPS = 2516.6  # dense bf16 (v_mfma_f32_32x32x16_bf16), --dtype bf16 runs
@@ -107,6 +194,10 @@ def parse():
                    help='skip the train() runs fed from host memory (train_loop in the JSON line)')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--cpu-samples', type=int, default=2)
+    p.add_argument('--launch-only', action='store_true',
+                   help='print this rank\'s view of the launch (rank, world size, rendezvous) as '
+                        'one JSON line and exit without touching the GPU: the CPU test of the '
+                        'self-launcher')
     return p.parse_args()
 
 
@@ -607,18 +698,30 @@ def main():
         a.executor = True
     launch_mode = (a.graph, a.executor)
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if a.launch_only:
+        print(json.dumps({'rank': int(os.environ.get('RANK', '0')), 'world': world,
+                          'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'gpus': a.gpus,
+                          'master': f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}),
+              flush=True)
+        return
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world} in the environment')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    have = torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+    if local >= have:
+        raise SystemExit(f'bench.py: rank {os.environ.get("RANK", "0")} of {world} needs GPU {local}, '
+                         f'this machine shows {have}: one process per GPU, no rank can start')
     from dvs_of_training_framework_amd import parallel
     rank, local, world = parallel.init_distributed('cuda')
-    if world != a.gpus:
-        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with '
-                         'torch.distributed.run --nproc-per-node N')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     h = Harness(a, rank, device)
     if world > 1 or os.environ.get('DVSOF_FORCE_DIST') == '1':
         parallel.broadcast_parameters(h.model)
-        # DVSOF_DIRECT_RCCL=1: the C ABI's own communicator (dvsof_allreduce_bucket)
-        h.reducer = parallel.GradReducer(direct=os.environ.get('DVSOF_DIRECT_RCCL') == '1')
+        # ONE communicator -- the C ABI's own (dvsof_comm_create, made here) -- carries the
+        # exchange of replayed and eager steps alike; DVSOF_DIRECT_RCCL=0 with --eager:
+        # torch.distributed's process group instead (comparison runs)
+        h.reducer = parallel.GradReducer()
         h.model.predictor.reducer = h.reducer
 
     def barrier():
@@ -667,6 +770,15 @@ def main():
                     a.events or a.height * a.width,
                 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
         }
+        if h.reducer is not None:
+            # what the communicator that carried the exchange says it spans (ncclCommCount of
+            # the C ABI's communicator; the process group's size on the torch.distributed path)
+            info = h.reducer.comm_info()
+            out['config']['rccl_ranks'] = info['ranks'] if info else torch.distributed.get_world_size()
+            out['config']['exchange'] = (
+                f"{info['calls']} bucket all-reduces ({info['elements'] * 4 / 1e6:.1f} MB) on the C ABI's "
+                'RCCL communicator (dvsof_allreduce_bucket)' if info else
+                f'{h.reducer.bytes_reduced / 1e6:.1f} MB through torch.distributed (process group nccl)')
     if rank == 0:
         out['config']['launch'] = getattr(h, 'launch_fallback', None) or \
             'eager: every kernel enqueued from Python'

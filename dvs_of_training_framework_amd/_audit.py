@@ -57,6 +57,14 @@ def kernel_layouts():
         return _LAYOUTS
     import tempfile
     import yaml
+    # dvsof_exec_node_arg is unchecked: the layouts must describe the library that is
+    # LOADED (a rebuilt libdvsof_hip.so on disk under a running process would make the
+    # argument indices / sizes below an out-of-bounds host read)
+    _lib.lib()
+    st = Path(_lib.LIB_PATH).stat()
+    if (st.st_ino, st.st_size, st.st_mtime_ns) != _lib.LOADED_STAT:
+        raise RuntimeError(f'{_lib.LIB_PATH} changed on disk since it was loaded: its '
+                           'code-object metadata no longer describes the loaded kernels')
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for i, blob in enumerate(_code_objects(_lib.LIB_PATH)):
@@ -160,4 +168,62 @@ def audit_step(step):
                     res['unheld'].append((i - 1, name[:60], k, hex(w)))
                 else:
                     res[kind] += 1
+    return res
+
+
+def audit_exchange(step):
+    """The rule the executor's BUCKET marks rely on (csrc/exec.hip): a kernel
+    captured behind a bucket's exchange mark, but not behind its WAIT / the
+    JOIN mark, inherits the mark's dependencies and may run BESIDE the
+    collective -- so it must not carry a pointer into that bucket.  True today
+    by construction (``Predictor._grad_targets`` closes a bucket behind its
+    last writer, the next reader is the optimizer behind the WAIT / JOIN
+    mark); checked at every recording that has marks, because at one rank the
+    collective is an identity and a violation would change nothing there.
+    -> {'marks', 'window_kernels', 'checked_pointers', 'violations': [...],
+    'foreign': [...]}; capture.py refuses the recording on a violation."""
+    x = step.executor
+    assert x is not None
+    layouts = kernel_layouts()
+    lib = _lib.lib()
+    res = {'marks': 0, 'window_kernels': 0, 'checked_pointers': 0, 'violations': [],
+           'foreign': []}
+    names = {}
+
+    def name_of(i):
+        if i not in names:
+            buf = ctypes.create_string_buffer(2048)
+            _lib.check(lib.dvsof_exec_node(x._handle, i, None, None, None, buf, 2048),
+                       'dvsof_exec_node')
+            names[i] = buf.value.decode(errors='replace')
+        return names[i]
+    k = 0
+    while True:
+        ptr, n, index, count = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
+        cap = 4096
+        nodes = (ctypes.c_int * cap)()
+        if lib.dvsof_exec_mark_window(x._handle, k, ctypes.byref(ptr), ctypes.byref(n),
+                                      ctypes.byref(index), nodes, cap, ctypes.byref(count)) != 0:
+            break
+        k += 1
+        res['marks'] += 1
+        lo = ptr.value or 0
+        hi = lo + 4 * n.value
+        for i in list(nodes)[:min(count.value, cap)]:
+            name = name_of(i)
+            res['window_kernels'] += 1
+            args = layouts.get(name)
+            if args is None:        # not one of ours (ATen): never handed a gradient bucket
+                if name[:80] not in res['foreign']:
+                    res['foreign'].append(name[:80])
+                continue
+            for a, (size, is_ptr) in enumerate(args):
+                if size < 8:
+                    continue
+                raw = x.node_arg(i, a, size)
+                words = struct.unpack_from(f'<{size // 8}Q', raw)
+                for w in (words[:1] if is_ptr else words):
+                    res['checked_pointers'] += 1
+                    if lo <= w < hi:
+                        res['violations'].append((index.value, i, name[:60], a, hex(w)))
     return res

@@ -39,6 +39,10 @@ _SIGNATURES = {
     'dvsof_comm_create': (_i, [ctypes.POINTER(_vp), _i, _i, _vp]),
     'dvsof_comm_destroy': (_i, [_vp]),
     'dvsof_allreduce_bucket': (_i, [_vp, _vp, _sz, _vp]),
+    'dvsof_comm_create_loopback': (_i, [ctypes.POINTER(_vp), _i, _i]),
+    'dvsof_comm_info': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i),
+                             ctypes.POINTER(ctypes.c_ulonglong),
+                             ctypes.POINTER(ctypes.c_ulonglong)]),
     'dvsof_exec_create': (_i, [_vp, ctypes.POINTER(_vp), _i,
                                ctypes.POINTER(_vp)]),
     'dvsof_exec_info': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i),
@@ -54,6 +58,10 @@ _SIGNATURES = {
     'dvsof_exec_set_comm': (_i, [_vp, _vp, _vp]),
     'dvsof_exec_marks': (_i, [_vp, ctypes.POINTER(_i)]),
     'dvsof_exec_node_arg': (_i, [_vp, _i, _i, _sz, _vp]),
+    'dvsof_exec_mark_window': (_i, [_vp, _i, ctypes.POINTER(_vp),
+                                    ctypes.POINTER(_sz), ctypes.POINTER(_i),
+                                    ctypes.POINTER(_i), _i,
+                                    ctypes.POINTER(_i)]),
     'dvsof_count_image': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     'dvsof_voxelize_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                 _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -89,6 +97,7 @@ _SIGNATURES = {
 }
 
 _lib = None
+LOADED_STAT = None
 
 
 def declared_symbols():
@@ -115,6 +124,9 @@ def lib():
                 '`make -C dvs_of_training_framework_amd/csrc`. '
                 'There is no CPU fallback for the HIP hot path.')
         _lib = ctypes.CDLL(str(LIB_PATH))
+        st = LIB_PATH.stat()
+        global LOADED_STAT      # the file these code objects came from (_audit.py)
+        LOADED_STAT = (st.st_ino, st.st_size, st.st_mtime_ns)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.restype, fn.argtypes = res, args

@@ -226,6 +226,12 @@ class CapturedTrainStep:
         exchanging = reducer is not None and self.closes and self._would_exchange()
         assert executor or not exchanging, \
             'the gradient exchange of a captured step is issued by the step executor'
+        if reducer is not None and self._would_exchange():
+            # one communicator for replays AND the eager micro-batches around them (this
+            # constructor's own, re-recordings, other signatures, the fall-back after a failed
+            # recording); a collective call when the communicator is still to be made, so it
+            # happens here -- before anything rank-local can go wrong -- not after the recording
+            reducer.adopt_direct()
         if getattr(optimizer, '_use_dyn', False):
             optimizer.end_capture()      # another captured step shares the optimizer
         ev = example_batch['events']
@@ -350,6 +356,13 @@ class CapturedTrainStep:
             red = self.reducer
             if self.executor.marks:
                 assert red is not None
+                # kernels the executor lets run beside a bucket's collective must not touch
+                # the bucket (csrc/exec.hip, _audit.audit_exchange)
+                from ._audit import audit_exchange
+                self.exchange_audit = audit_exchange(self)
+                if self.exchange_audit['violations']:
+                    raise RuntimeError('a kernel inside the exchange window of a gradient bucket '
+                                       f"takes a pointer into it: {self.exchange_audit['violations'][:4]}")
                 self.executor.set_comm(red.comm_handle(), red.exchange_stream(dev))
 
     # ------------------------------------------------------------ the batch
@@ -443,6 +456,9 @@ class CapturedLoop:
         self.bound = {}         # (role, slot, generation) -> step bound to a feeder slot
         self.failed = None      # CaptureFailed of the role that could not be recorded
         self.recaptures = 0
+        if reducer is not None and torch.device(device).type == 'cuda' and \
+                (reducer.world > 1 or reducer.loopback is not None):
+            reducer.adopt_direct()      # collective: every rank builds its loop at the same point
 
     def any(self):
         return next(iter(self.steps.values()), None)

@@ -68,6 +68,8 @@ struct XNode {
     int lane0 = 0;           // lane of the greedy chain split made at creation
     float us = 1.f;          // measured duration (dvsof_exec_calibrate)
     std::vector<int> deps_id;    // ids of the nodes this one depends on
+    std::vector<int> window;     // BUCKET mark: ids of the kernels captured behind it that are NOT
+                                 // behind its WAIT / the JOIN mark (they must not touch the bucket)
     std::vector<int> deps;   // their positions in the current launch order
     std::vector<int> wait;   // nodes of other lanes to wait for before the launch
     hipEvent_t ev;           // recorded after the launch when another lane waits for it
@@ -402,6 +404,29 @@ int dvsof_exec_marks(void *exec, int *n_marks)
     return DVSOF_OK;
 }
 
+int dvsof_exec_mark_window(void *exec, int k, float **bucket, size_t *n, int *index, int *nodes, int cap,
+                           int *count)
+{
+    if (!exec || k < 0 || !count || cap < 0 || (cap > 0 && !nodes)) return DVSOF_EINVAL;
+    Exec *x = (Exec *)exec;
+    const int nn = (int)x->nodes.size();
+    std::vector<int> by_id(nn);
+    for (int i = 0; i < nn; ++i) by_id[x->nodes[i].id] = i;
+    // the k-th BUCKET mark in capture order
+    std::vector<int> marks;
+    for (int i = 0; i < nn; ++i)
+        if (x->nodes[i].mark == DVSOF_MARK_BUCKET) marks.push_back(x->nodes[i].id);
+    std::sort(marks.begin(), marks.end());
+    if (k >= (int)marks.size()) return DVSOF_EINVAL;
+    const XNode &m = x->nodes[by_id[marks[k]]];
+    if (bucket) *bucket = m.mark_ptr;
+    if (n) *n = m.mark_n;
+    if (index) *index = m.mark_index;
+    *count = (int)m.window.size();
+    for (int j = 0; j < *count && j < cap; ++j) nodes[j] = by_id[m.window[j]];
+    return DVSOF_OK;
+}
+
 int dvsof_exec_node_arg(void *exec, int i, int arg, size_t nbytes, void *out)
 {
     if (!exec || !out) return DVSOF_EINVAL;
@@ -524,6 +549,48 @@ int dvsof_exec_create(void *graph_, void *const *side_streams, int n_side, void 
         n.id = (int)i;
         tail[lane] = (int)i;
         n.deps = n.deps_id = deps;
+    }
+    // The exchange window of every BUCKET mark, from the dependencies AS CAPTURED: the kernels
+    // that follow the mark in the capture but neither its WAIT mark nor (without one) the JOIN
+    // mark.  The rewrite below lets exactly these run beside the collective, which is only
+    // right when none of them reads or writes the bucket -- dvsof_exec_mark_window hands the
+    // set to the caller, who knows the kernels' argument layouts (capture.py refuses the
+    // recording when one of them carries a pointer into the bucket).
+    {
+        std::vector<std::vector<int>> succ(nn);
+        for (size_t i = 0; i < nn; ++i)
+            for (int d : x->nodes[i].deps_id) succ[d].push_back((int)i);
+        auto reach = [&](int from, std::vector<char> &seen) {
+            std::vector<int> todo{from};
+            seen[from] = 1;
+            while (!todo.empty()) {
+                const int v = todo.back();
+                todo.pop_back();
+                for (int s_ : succ[v])
+                    if (!seen[s_]) {
+                        seen[s_] = 1;
+                        todo.push_back(s_);
+                    }
+            }
+        };
+        for (size_t m = 0; m < nn; ++m) {
+            XNode &mk = x->nodes[m];
+            if (mk.mark != DVSOF_MARK_BUCKET) continue;
+            std::vector<char> behind(nn, 0), safe(nn, 0);
+            reach((int)m, behind);
+            bool has_wait = false;
+            for (size_t j = 0; j < nn; ++j)
+                if (x->nodes[j].mark == DVSOF_MARK_WAIT && x->nodes[j].mark_index == mk.mark_index) {
+                    has_wait = true;
+                    reach((int)j, safe);
+                }
+            if (!has_wait)
+                for (size_t j = 0; j < nn; ++j)
+                    if (x->nodes[j].mark == DVSOF_MARK_JOIN && behind[j]) reach((int)j, safe);
+            for (size_t j = 0; j < nn; ++j)
+                if (j != m && behind[j] && !safe[j] && x->nodes[j].kernel && !x->nodes[j].mark)
+                    mk.window.push_back((int)j);
+        }
     }
     // A BUCKET mark is a side effect of its stream, not a producer: what follows it in the
     // capture follows what PRECEDED it.  Kernels inherit the mark's dependencies instead of

@@ -92,12 +92,31 @@ def init_distributed(device_type='cuda'):
 class GradReducer:
     """Averages gradient buckets across ranks, overlapped with backward.
 
-    direct=True: the collective is ``dvsof_allreduce_bucket`` of the C ABI (its
-    own RCCL communicator, created here from a unique id that rank 0 shares
-    through the process group) instead of ``torch.distributed.all_reduce`` --
-    the same exchange, enqueued straight on the exchange stream."""
+    ONE communicator carries the exchange on every path of a run (round-3
+    advisor finding: captured steps exchanged on the C ABI's communicator, the
+    eager micro-batches around them -- re-recordings, other signatures, the
+    fall-back after a failed capture -- on torch.distributed's, and those
+    decisions are rank-local, so collectives of two communicators interleaved
+    differently on different ranks):
 
-    def __init__(self, group=None, direct=False):
+    direct=True  (default on a GPU with an 'nccl' process group): the C ABI's
+        own RCCL communicator (``dvsof_comm_create`` from a unique id rank 0
+        shares through the process group), created HERE -- a collective call,
+        at a point every rank passes -- and used by the eager loop
+        (``dvsof_allreduce_bucket`` on the exchange stream) and by the step
+        executor's marks alike.  Every closing micro-batch issues the same 8
+        bucket all-reduces in the same order whatever launch mode its rank is
+        in, which is all RCCL needs.
+    direct=False  ``torch.distributed.all_reduce`` on the process group (gloo on
+        the CPU tests; ``DVSOF_DIRECT_RCCL=0`` on a GPU for comparison runs --
+        a captured step then switches the reducer to direct, see
+        ``adopt_direct``).
+    loopback=(world, delay_us)  or DVSOF_LOOPBACK="world:delay_us": the loopback
+        communicator of ``dvsof_comm_create_loopback`` -- no peers, the average
+        with world - 1 all-zero buckets, delay_us late: the ordering tests of
+        the exchange on one GPU."""
+
+    def __init__(self, group=None, direct=None, loopback=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.enabled = True          # False on non-boundary micro-batches
@@ -105,19 +124,52 @@ class GradReducer:
         self._side = None
         self.bytes_reduced = 0
         self._comm = None
-        self._direct = direct
         self._events = {}            # bucket address -> its "ready" event, reused every step
         self._marked = 0             # marks left in the capture in progress
-        if direct:
+        if loopback is None and os.environ.get('DVSOF_LOOPBACK'):
+            w, _, us = os.environ['DVSOF_LOOPBACK'].partition(':')
+            loopback = (int(w), int(us or 50))
+        self.loopback = tuple(loopback) if loopback else None
+        if direct is None:
+            direct = self.loopback is not None or (
+                dist.is_initialized() and dist.get_backend(group) == 'nccl'
+                and os.environ.get('DVSOF_DIRECT_RCCL', '1') != '0')
+        self._direct = bool(direct)
+        if self._direct:
             self._comm = self._make_comm()
 
     def comm_handle(self):
-        """The C ABI's RCCL communicator (dvsof_comm_create), made on first
-        use -- a COLLECTIVE call: every rank gets here at the same point (the
-        first captured step that exchanges gradients)."""
+        """The C ABI's communicator.  Made in the constructor of a direct
+        reducer; on first use otherwise -- a COLLECTIVE call then: every rank
+        must get here at the same point (capture.py calls ``adopt_direct``
+        before it runs or records anything)."""
         if self._comm is None:
             self._comm = self._make_comm()
         return self._comm
+
+    def adopt_direct(self):
+        """From now on the eager path exchanges on the C ABI's communicator too
+        (called by the captured step / loop before its first micro-batch, so
+        that replays and the eager micro-batches around them share one
+        communicator).  Collective when the communicator does not exist yet."""
+        if not self._direct:
+            assert not self.pending, 'adopt_direct between steps only'
+            self.comm_handle()
+            self._direct = True
+
+    def comm_info(self):
+        """{'ranks', 'loopback', 'calls', 'elements'} of the C ABI's
+        communicator (ranks = ncclCommCount), or None without one."""
+        if self._comm is None:
+            return None
+        import ctypes
+        from . import _lib
+        r, lb = ctypes.c_int(), ctypes.c_int()
+        c, e = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        _lib.check(_lib.lib().dvsof_comm_info(self._comm, ctypes.byref(r), ctypes.byref(lb),
+                                              ctypes.byref(c), ctypes.byref(e)), 'dvsof_comm_info')
+        return {'ranks': r.value, 'loopback': bool(lb.value), 'calls': c.value,
+                'elements': e.value}
 
     def exchange_stream(self, device):
         """Stream of the collectives.  DVSOF_EXCHANGE_ON_WGRAD_STREAM=1: the
@@ -135,6 +187,11 @@ class GradReducer:
         import ctypes
         from . import _lib
         lib = _lib.lib()
+        comm = ctypes.c_void_p()
+        if self.loopback is not None:
+            _lib.check(lib.dvsof_comm_create_loopback(ctypes.byref(comm), *self.loopback),
+                       'dvsof_comm_create_loopback')
+            return comm
         rank = dist.get_rank(self.group) if dist.is_initialized() else 0
         ident = ctypes.create_string_buffer(128)
         if rank == 0:
@@ -143,7 +200,6 @@ class GradReducer:
             box = [ident.raw]
             dist.broadcast_object_list(box, src=0, group=self.group)
             ident = ctypes.create_string_buffer(box[0], 128)
-        comm = ctypes.c_void_p()
         with _stdout_to_stderr():        # RCCL's banner, as in init_distributed
             _lib.check(lib.dvsof_comm_create(ctypes.byref(comm), self.world, rank,
                                              ident), 'dvsof_comm_create')
@@ -166,7 +222,7 @@ class GradReducer:
 
     def active(self):
         """Does bucket_ready exchange anything?"""
-        return self.enabled and (self.world > 1 or
+        return self.enabled and (self.world > 1 or self.loopback is not None or
                                  os.environ.get('DVSOF_FORCE_DIST') == '1')
 
     def bucket_ready(self, flat, after=None):

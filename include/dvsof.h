@@ -604,6 +604,22 @@ int dvsof_comm_create(void **comm, int world_size, int rank,
                       const void *host_id128);
 int dvsof_comm_destroy(void *comm);
 int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
+/* dvsof_comm_info: ranks = what the communicator spans (ncclCommCount for an
+ * RCCL communicator -- bench.py prints it as config.rccl_ranks), loopback = 1
+ * for a loopback communicator, calls / elements = dvsof_allreduce_bucket calls
+ * issued on it so far and the floats they carried (any pointer may be NULL).
+ *
+ * dvsof_comm_create_loopback: a communicator WITHOUT peers, for the ordering
+ * tests of the exchange on one GPU: the other world_size - 1 ranks are
+ * imaginary and contribute all-zero buckets, the wire is a spin of delay_us on
+ * `stream`.  dvsof_allreduce_bucket then leaves bucket / world_size in place,
+ * delay_us late -- an exchange that is neither the identity nor instantaneous
+ * (a 1-rank RCCL group launches nothing at all), so a kernel that reads or
+ * rewrites a bucket on the wrong side of its collective changes the result.
+ * No RCCL involved; never used by a training run. */
+int dvsof_comm_info(void *comm, int *ranks, int *loopback,
+                    unsigned long long *calls, unsigned long long *elements);
+int dvsof_comm_create_loopback(void **comm, int world_size, int delay_us);
 
 /* ------------------------------------------------------------------ *
  * Step executor (csrc/exec.hip): the loop body of the reference's train()
@@ -659,7 +675,12 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
  *   dvsof_exec_marks   number of marks found in the graph
  *   dvsof_exec_node_arg  copies the first nbytes of kernel argument `arg` of
  *                      node i (launch order) -- diagnostics: the pointer audit
- *                      of capture.CapturedTrainStep.audit
+ *                      of capture.CapturedTrainStep.audit.  UNCHECKED: a node
+ *                      does not know its argument count or sizes (the HIP
+ *                      graph API does not expose them); the caller takes both
+ *                      from the code-object metadata of the SAME library file
+ *                      that is loaded (_audit.py verifies that) -- a wrong
+ *                      arg / nbytes is an out-of-bounds host read
  * Every rank replays the same graph, so the collectives are issued in the
  * same order everywhere.
  * ------------------------------------------------------------------ */
@@ -669,6 +690,15 @@ int dvsof_allreduce_bucket(void *comm, float *bucket, size_t n, void *stream);
 int dvsof_exec_mark(int kind, int index, float *bucket, size_t n, void *stream);
 int dvsof_exec_set_comm(void *exec, void *comm, void *exchange_stream);
 int dvsof_exec_marks(void *exec, int *n_marks);
+/* The exchange window of the k-th BUCKET mark (capture order): the kernels
+ * captured behind the mark that are not behind its WAIT mark (or, without one,
+ * the JOIN mark).  They inherit the mark's dependencies and may run beside
+ * the collective, so none of them may touch [bucket, bucket + n).  nodes[] =
+ * their positions in the launch order (at most cap; *count = how many there
+ * are).  The caller checks the arguments (capture.py at recording time, with
+ * the argument layouts of the code objects); DVSOF_EINVAL past the last mark. */
+int dvsof_exec_mark_window(void *exec, int k, float **bucket, size_t *n,
+                           int *index, int *nodes, int cap, int *count);
 int dvsof_exec_node_arg(void *exec, int i, int arg, size_t nbytes, void *out);
 int dvsof_exec_create(void *graph, void *const *side_streams, int n_side,
                       void **exec);

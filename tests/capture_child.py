@@ -223,14 +223,22 @@ def scenario_infer():
 
 
 def _dist():
-    """1-rank RCCL group when the test asks for it (DVSOF_FORCE_DIST=1)."""
+    """1-rank RCCL group when the test asks for it (DVSOF_FORCE_DIST=1), or the
+    loopback communicator (DVSOF_LOOPBACK="world:delay_us": average with
+    world - 1 all-zero buckets, delay_us late -- NOT an identity, so a kernel
+    on the wrong side of a collective changes the weights)."""
     import os
+    from dvs_of_training_framework_amd import parallel
+    if os.environ.get('DVSOF_LOOPBACK'):
+        parallel.claim_streams('cuda')
+        red = parallel.GradReducer()
+        assert red.active() and red.comm_info()['loopback']
+        return red
     if os.environ.get('DVSOF_FORCE_DIST') != '1':
         return None
-    from dvs_of_training_framework_amd import parallel
     parallel.init_distributed('cuda')
     red = parallel.GradReducer()
-    assert red.active()
+    assert red.active() and red.comm_info()['ranks'] == 1
     return red
 
 
@@ -305,16 +313,29 @@ def scenario_big(dtype):
         torch.cuda.synchronize()
         x = caps[0].executor
         info.update(kernels=x.kernels, lanes=x.lanes, lane_kernels=x.lane_kernels, marks=x.marks,
-                    host_ms_per_step=round(host / 4 * 1e3, 3))
+                    host_ms_per_step=round(host / 4 * 1e3, 3),
+                    exchange_audit=getattr(caps[0], 'exchange_audit', None))
         for c in caps.values():
             c.close()
         return [float(v) for v in losses], weights
+    calls = []
     l_e, w_e = eager()
+    calls.append(red.comm_info()['calls'] if red is not None else 0)
     l_r, w_r = replayed()
+    calls.append(red.comm_info()['calls'] - calls[0] if red is not None else 0)
+    ci = red.comm_info() if red is not None else None
     if red is not None:
         red.close()
+    # the exchange does something: under the loopback communicator the weights differ from a
+    # run without any exchange (else "bit-identical" would say nothing about ordering)
+    moved = None
+    if ci and ci['loopback']:
+        red = None
+        _, w_plain = eager()
+        moved = not all(torch.equal(a, b) for a, b in zip(w_e, w_plain))
     return {'losses_equal': l_e == l_r, 'weights_equal': all(torch.equal(a, b) for a, b in zip(w_e, w_r)),
-            'eager': l_e, 'replayed': l_r, 'executor': info, 'dist': red is not None,
+            'eager': l_e, 'replayed': l_r, 'executor': info, 'dist': ci is not None,
+            'comm': ci, 'calls': calls, 'exchange_changes_weights': moved,
             'max_weight_diff': max(float((a - b).abs().max()) for a, b in zip(w_e, w_r))}
 
 
@@ -422,13 +443,31 @@ def scenario_compact():
     return _compare(data)
 
 
-def scenario_grow():
+def scenario_grow(dp=False):
+    """dp: under the reducer.  A rank whose batch outgrows its event capacity
+    re-records (an eager micro-batch + a calibration step) while its peers go
+    on replaying -- a rank-local decision.  What keeps the ranks' collectives
+    paired is that EVERY mode issues the same bucket all-reduces on the same
+    communicator: the call count per optimizer step is the same for the eager
+    loop and for the capture loop with its two re-recordings."""
     B, H, W = 2, 64, 64
     # events per sample; capacities 8192 -> 16384 -> 32768 (all on the tiled
     # voxeliser, which is bitwise reproducible whatever the event order)
     counts = [2100, 4000, 6000, 5000, 2100, 12000]
     data = [synthetic.make_batch(500 + i, B, H, W, c) for i, c in enumerate(counts)]
-    return _compare(data)
+    red = _dist() if dp else None
+    if red is None:
+        return _compare(data)
+    r0, w0, _ = _train_rows(data, False, red=red)
+    c0 = red.comm_info()
+    r1, w1, info = _train_rows(data, True, red=red)
+    c1 = red.comm_info()
+    red.close()
+    return {'rows_equal': r0 == r1, 'n_rows': len(r0),
+            'weights_equal': all(torch.equal(a, b) for a, b in zip(w0, w1)), 'info': info,
+            'calls_eager': c0['calls'], 'calls_capture': c1['calls'] - c0['calls'],
+            'elements_eager': c0['elements'], 'elements_capture': c1['elements'] - c0['elements'],
+            'steps': len(data)}
 
 
 def scenario_fail():
@@ -480,7 +519,7 @@ if __name__ == '__main__':
     out = {'train': scenario_train, 'train_graph': lambda: scenario_train(False),
            'loop': scenario_loop, 'bind': scenario_bind, 'infer': scenario_infer,
            'big': lambda: scenario_big(arg or 'f32'), 'accum': lambda: scenario_accum(arg == 'dp'),
-           'compact': scenario_compact, 'grow': scenario_grow, 'feed': lambda: scenario_feed(int(arg or 1)), 'fail': scenario_fail,
+           'compact': scenario_compact, 'grow': lambda: scenario_grow(arg == 'dp'), 'feed': lambda: scenario_feed(int(arg or 1)), 'fail': scenario_fail,
            'audit': scenario_audit}[name]()
     print(json.dumps(out), flush=True)
     _shutdown()

@@ -15,8 +15,11 @@ pytestmark = pytest.mark.gpu
 CHILD = Path(__file__).resolve().parent / 'capture_child.py'
 
 
-def run(scenario, dist=False):
+def run(scenario, dist=False, loopback=None):
     env = dict(os.environ)
+    env.pop('DVSOF_LOOPBACK', None)
+    if loopback:    # "world:delay_us": the loopback communicator (no process group)
+        env['DVSOF_LOOPBACK'] = loopback
     if dist:        # a 1-rank nccl (= RCCL) group in the child: the real exchange path
         env.update(DVSOF_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', RANK='0', WORLD_SIZE='1',
                    LOCAL_RANK='0', MASTER_PORT=str(29500 + os.getpid() % 2000),
@@ -116,6 +119,60 @@ def test_executor_with_the_optimizer_inside_the_backward(dist):
     x = r['executor']
     # 8 bucket marks + 8 wait marks (one in front of every bucket's update) + the join mark
     assert x['kernels'] >= 120 and x['marks'] == (17 if dist else 0), x
+
+
+@pytest.mark.parametrize('scenario', ['big:f32', 'big:bf16s', 'big:f32:fused'])
+def test_executor_orders_a_non_identity_exchange_like_the_eager_loop(scenario):
+    """The ordering test the 1-rank group cannot give (there RCCL launches
+    nothing and the average is the identity, so a missing edge between a
+    collective and AdamW / the next weight gradient changes no bit).  Loopback
+    communicator, world 2, 50 us late: every bucket comes back HALVED 50 us
+    after its gradients were final.  Executor replays (marks -> the collective
+    on the exchange stream, kernels behind a BUCKET mark running beside it,
+    WAIT / JOIN marks in front of the updates) == the eager loop with the same
+    communicator, bit for bit, at the benchmark shape; with the optimizer
+    inside the backward each bucket's update sits behind ITS collective only.
+    The recording-time audit finds no kernel inside an exchange window that
+    takes a pointer into the window's bucket."""
+    r = run(scenario, loopback='2:50')
+    assert r['dist'] and r['comm']['loopback'] and r['comm']['ranks'] == 2, r
+    assert r['exchange_changes_weights'] is True, r
+    assert r['losses_equal'] and r['weights_equal'], r
+    x = r['executor']
+    assert x['marks'] == (17 if scenario.endswith('fused') else 9), x
+    a = x['exchange_audit']
+    assert a['marks'] == 8 and a['violations'] == [], a
+    if scenario.endswith('fused'):  # a WAIT mark right behind every BUCKET mark: empty windows
+        assert a['window_kernels'] == 0, a
+    else:       # everything between a bucket's close and the JOIN mark runs beside its collective
+        assert a['window_kernels'] > 50 and a['checked_pointers'] > 200, a
+    # 8 buckets per step, eager and replayed alike
+    assert r['calls'][0] == 8 * 4 and r['calls'][1] % 8 == 0 and r['calls'][1] >= 8 * 4, r['calls']
+
+
+def test_accumulation_under_a_non_identity_exchange():
+    """train(accumulation_steps=3) under the loopback communicator: the roles
+    first / middle write and accumulate into the buckets while nothing is
+    exchanged, 'last' exchanges and updates -- and the NEXT step's 'first'
+    must not rewrite a bucket before its late collective is done."""
+    r = run('accum:dp', loopback='2:80')
+    assert r['n_rows'] > 0 and r['rows_equal'] and r['weights_equal'], r
+    assert r['info']['roles'] == ['first', 'last', 'middle'] and r['info']['replays'] >= 5, r
+
+
+def test_rerecording_rank_issues_the_same_collectives_as_a_replaying_one():
+    """Round-3 advisor finding: re-recording at a larger event capacity (and
+    every other switch between replay and eager) is a rank-local decision; the
+    ranks stay paired because every mode issues the same 8 bucket all-reduces
+    per optimizer step on ONE communicator (parallel.GradReducer: the C ABI's,
+    adopted before the first micro-batch).  Capture loop with two
+    re-recordings vs the eager loop: same call count, same elements, same
+    weights -- under the non-identity loopback exchange."""
+    r = run('grow:dp', loopback='2:30')
+    assert r['rows_equal'] and r['weights_equal'], r
+    assert r['info']['recaptures'] == 2 and r['info']['failed'] is None, r
+    assert r['calls_eager'] == r['calls_capture'] == 8 * r['steps'], r
+    assert r['elements_eager'] == r['elements_capture'], r
 
 
 @pytest.mark.parametrize('dp', [False, True])
