@@ -193,7 +193,8 @@ def parse():
     p.add_argument('--no-train-loop', action='store_true',
                    help='skip the train() runs fed from host memory (train_loop in the JSON line)')
     p.add_argument('--no-roofline', action='store_true')
-    p.add_argument('--cpu-samples', type=int, default=2)
+    p.add_argument('--cpu-samples', type=int, default=8,
+                   help='samples per step of the cpu_baseline leg (of --batch)')
     p.add_argument('--launch-only', action='store_true',
                    help='print this rank\'s view of the launch (rank, world size, rendezvous) as '
                         'one JSON line and exit without touching the GPU: the CPU test of the '
@@ -330,36 +331,6 @@ def executed_flops(desc, kind):
     if m:   # (m+2)^2 products per m x m outputs instead of 9 m^2
         return f * (m + 2) ** 2 / (9.0 * m * m)
     return f
-
-
-def recorded_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed
-    rocprofv3 PMC passes (profiles/round*/..._traffic_pmc.csv, made by
-    tools/pmc_traffic.py: FETCH_SIZE x2 for the gfx950 under-count +
-    WRITE_SIZE, separate --pmc runs of tools/conv_bench.py on this workload).
-    Hardware counters cannot be read from inside this process, so the bench
-    line's `traffic` is null and this RECORDED figure sits beside it with its
-    source; it goes stale when a kernel changes."""
-    import csv
-    files = sorted((ROOT / 'profiles').glob('round*/*traffic_pmc.csv'))
-    if not files:
-        return None
-    path = files[-1]
-    prefix = kernel.split('>')[0]          # e.g. gconv2_kernel<2,2,1,1
-    num = den = 0.0
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            if row['k'].endswith(',1>') and row['k'].count(',') in (8, 5):
-                continue        # TAG = 1 instantiations: Winograd component GEMMs
-            if row['k'].startswith(prefix + ',') or row['k'] == prefix + '>':
-                n = float(row['n'])
-                num += n * (float(row['fetch_MB']) + float(row['write_MB'])) * 1e6
-                den += n
-    if not den:
-        return None
-    return {'bytes_per_launch': round(num / den),
-            'source': str(path.relative_to(ROOT)) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
-                      'passes, FETCH x2 on gfx950)'}
 
 
 PEAK_HBM_TBS = 8.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -536,8 +507,9 @@ def measure_roofline(h, step_ms, steps=3, light=False):
         'bound': 'mfma', 'kernel': dom,
         'achieved': round(xfl / sec / T, 2), 'peak': peak, 'unit': 'TFLOP/s',
         'frac': round(xfl / sec / T / peak, 4),
-        'traffic': None,        # PMC counters are not readable in-process
-        'traffic_recorded': recorded_traffic(dom),
+        # HBM-side bytes come from hardware counters, which a process cannot read about
+        # itself: the rocprofv3 --pmc passes of this command are under profiles/ (README there)
+        'traffic': None,
         'avg_launch_us': round(sec / n * 1e6, 2),
         'gflop_per_launch_executed': round(xfl / n / 1e9, 3),
         'gflop_per_launch_algorithmic': round(fl / n / 1e9, 3),
@@ -559,58 +531,115 @@ def measure_roofline(h, step_ms, steps=3, light=False):
     return roof
 
 
-def cpu_baseline(a):
-    """CPU port of the same training step (oracle/: C voxeliser + loss,
-    PyTorch-CPU restatement of the predictor, torch AdamW), timed on the host
-    cores over a bounded sample of the workload."""
+def host_cpu():
+    """(model string, physical cores usable by this process) from lscpu and
+    the affinity mask (a container may see fewer cores than the socket has)."""
+    import subprocess
+    model, per, sockets, threads_per = 'unknown', None, 1, 1
+    try:
+        for line in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'Model name':
+                model = v
+            elif k == 'Core(s) per socket':
+                per = int(v)
+            elif k == 'Socket(s)':
+                sockets = int(v)
+            elif k == 'Thread(s) per core':
+                threads_per = int(v)
+    except Exception:       # noqa: BLE001
+        pass
+    usable = len(os.sched_getaffinity(0))
+    physical = per * sockets if per else max(1, usable // max(threads_per, 1))
+    if usable < physical * threads_per:      # a CPU share: hardware threads it may run on
+        physical = max(1, usable // max(threads_per, 1))
+    return model, physical
+
+
+def cpu_step_rate(B, bins, H, W, events, threads, budget_s, net='evflownet', train=True):
+    """samples/s of the CPU port of one step at (B, bins, H, W) on `threads`
+    host threads (torch intra-op threads for the ATen predictor + AdamW,
+    OpenMP threads over samples for the C voxeliser / loss), over at most
+    ~budget_s seconds of timed steps after one warm-up step.
+    net='dummy': BASELINE.json configs[0] -- DummyNet (zero flows, no
+    parameters, DummyNet/net.py:59-80), forward + loss only (its output carries
+    no gradient: tests/training path)."""
     import numpy as np
     from oracle import cpu_oracle as orc
     from oracle.ref_model import ref_predictor
     from dvs_of_training_framework_amd import synthetic
     from dvs_of_training_framework_amd.predictor import Predictor
-    cores = torch.get_num_threads()
-    B = max(1, min(a.cpu_samples, a.batch))
-    torch.manual_seed(1234)
-    net = Predictor(a.bins)
-    state = {k: v.detach().clone().requires_grad_(True)
-             for k, v in net.state_dict().items()}
-    opt = torch.optim.AdamW(list(state.values()), lr=1e-3, weight_decay=1e-4,
-                            amsgrad=True)
-    batch = synthetic.make_batch(1234, B, a.height, a.width, a.events)
-    shapes = synthetic.scale_shapes(a.height, a.width)
+    torch.set_num_threads(threads)
+    orc.use_openmp(threads)
+    batch = synthetic.make_batch(1234, B, H, W, events)
+    shapes = synthetic.scale_shapes(H, W)
+    if net != 'dummy':
+        torch.manual_seed(1234)
+        state = {k: v.detach().clone().requires_grad_(True)
+                 for k, v in Predictor(bins).state_dict().items()}
+        opt = torch.optim.AdamW(list(state.values()), lr=1e-3, weight_decay=1e-4, amsgrad=True)
 
     def step():
         t0 = np.zeros(B, np.float32)
         t1 = np.full(B, synthetic.WINDOW, np.float32)
-        grid, _, _ = orc.voxelize(batch['events'], t0, t1, B, a.bins,
-                                  a.height, a.width)
-        flows = ref_predictor(state, torch.from_numpy(grid))
+        grid, _, _ = orc.voxelize(batch['events'], t0, t1, B, bins, H, W)
         ts = batch['timestamps'].reshape(B, 2)
-        _, loss, grads = orc.losses(
-            [f.detach().numpy() for f in flows], ts, np.arange(B),
-            batch['images'], batch['timestamps'], batch['sample_idx'])
-        torch.autograd.backward(flows, [torch.from_numpy(g) for g in grads])
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return loss
-    step()                                  # warm-up
-    per_step, t = [], time.perf_counter()
-    while len(per_step) < 3 or (time.perf_counter() - t < 15 and len(per_step) < 30):
-        t1 = time.perf_counter()
-        step()
-        per_step.append(time.perf_counter() - t1)
-    dt, n = time.perf_counter() - t, len(per_step)
+        if net == 'dummy':
+            flows = [np.zeros((B, 2, h, w), np.float32) for h, w in shapes]
+            orc.losses(flows, ts, np.arange(B), batch['images'], batch['timestamps'],
+                       batch['sample_idx'], with_grad=False)
+            return
+        flows = ref_predictor(state, torch.from_numpy(grid))
+        _, loss, grads = orc.losses([f.detach().numpy() for f in flows], ts, np.arange(B),
+                                    batch['images'], batch['timestamps'], batch['sample_idx'],
+                                    with_grad=train)
+        if train:
+            torch.autograd.backward(flows, [torch.from_numpy(g) for g in grads])
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+    try:
+        step()                              # warm-up
+        per_step, t = [], time.perf_counter()
+        while len(per_step) < 2 or (time.perf_counter() - t < budget_s and len(per_step) < 30):
+            t1 = time.perf_counter()
+            step()
+            per_step.append(time.perf_counter() - t1)
+        dt, n = time.perf_counter() - t, len(per_step)
+    finally:
+        orc.use_openmp(None)
     rate = sorted(B / x for x in per_step)
-    return {'value': round(B * n / dt, 3), 'unit': 'samples/s', 'cores': cores,
-            'kind': 'port',
-            # this figure moves with the host's load and thread placement
-            # (0.8-2.6 samples/s across boxes in round 1): the spread is stated
+    return {'value': round(B * n / dt, 3), 'unit': 'samples/s', 'threads': threads,
+            'steps': n, 'batch': B, 'seconds': round(dt, 1),
             'spread': {'min': round(rate[0], 3), 'median': round(rate[n // 2], 3),
-                       'max': round(rate[-1], 3)},
-            'sample': f'{n} steps of batch {B} (of {a.batch}) at '
-                      f'{a.height}x{a.width}x{a.bins}, {dt:.1f} s, '
-                      f'torch {cores} threads (ATen predictor + AdamW) + scalar '
-                      'single-thread C voxeliser/loss'}
+                       'max': round(rate[-1], 3)}}
+
+
+def cpu_baseline(a):
+    """CPU port of the same training step (oracle/: C voxeliser + loss with
+    OpenMP over samples, PyTorch-CPU restatement of the predictor, torch
+    AdamW), timed on the host cores over a bounded sample of the workload
+    (n in {1, all physical cores}, CPU model stated, configs 1 and
+    4 beside config 2)."""
+    model, physical = host_cpu()
+    B = max(1, min(a.cpu_samples, a.batch))
+    full = cpu_step_rate(B, a.bins, a.height, a.width, a.events, physical, 9.0)
+    one = cpu_step_rate(1, a.bins, a.height, a.width, a.events, 1, 1.0)
+    other = {
+        'configs[0] DummyNet 64x64x3, batch 4, forward + loss only (no parameters)':
+            cpu_step_rate(4, 3, 64, 64, None, physical, 1.0, net='dummy'),
+        'configs[3] EV_FlowNet 480x640x9, 307200 events/sample, batch 1 of 4 per GPU':
+            cpu_step_rate(1, 9, 480, 640, None, physical, 3.0),
+    }
+    return {'value': full['value'], 'unit': 'samples/s', 'cores': physical, 'kind': 'port',
+            'cpu_model': model, 'physical_cores': physical,
+            # this figure moves with the host's load and thread placement: the spread is stated
+            'spread': full['spread'],
+            'sample': f"{full['steps']} steps of batch {B} (of {a.batch}) at {a.height}x{a.width}x{a.bins}, "
+                      f"{full['seconds']} s, {physical} threads (ATen predictor + AdamW; C voxeliser / "
+                      'loss with OpenMP over samples)',
+            'threads': {'1': one, str(physical): full},
+            'other_configs': other}
 
 
 def train_loop_rates(a, device, steps=120, warm=30):

@@ -16,6 +16,8 @@ _PKG = Path(__file__).resolve().parent
 # DVSOF_GCONV_DBG / DVSOF_LOSS_DBG compiled in) -- diagnostics tools only
 LIB_PATH = _PKG / ('libdvsof_hip_probes.so' if os.environ.get('DVSOF_PROBE_LIB') == '1'
                    else 'libdvsof_hip.so')
+if os.environ.get('DVSOF_LIB_PATH'):    # an experiment's variant build (tools/variant.sh)
+    LIB_PATH = Path(os.environ['DVSOF_LIB_PATH']).resolve()
 HEADER_PATH = _PKG.parent / 'include' / 'dvsof.h'
 MAX_SCALES = 8
 

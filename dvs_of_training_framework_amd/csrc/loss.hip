@@ -186,8 +186,13 @@ __device__ __forceinline__ void final_terms(const Params &P, double (*s_tot)[3])
     }
 }
 
+#ifdef DVSOF_LOSS_WPE     // experiment (tools/variant.sh): registers capped for that many waves per SIMD
+#define LOSS_MAIN_ATTR __attribute__((amdgpu_waves_per_eu(DVSOF_LOSS_WPE, DVSOF_LOSS_WPE)))
+#else
+#define LOSS_MAIN_ATTR
+#endif
 template <bool FWD, bool BWD>
-__global__ __launch_bounds__(NT) void loss_main_kernel(const Params P)
+__global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Params P)
 {
     __shared__ float sF[2][LH][LW];
     __shared__ float red[NW][NPART];

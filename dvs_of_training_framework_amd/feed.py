@@ -72,6 +72,9 @@ class DeviceFeeder:
         to move (None: every column of the batch except ``element_index``,
         which no kernel of the model reads)."""
         self.loader, self.device = loader, torch.device(device)
+        # batch n+1 is staged BEFORE batch n is handed out: with one slot it would overwrite
+        # the batch the loop is about to train on
+        assert slots >= 2, 'DeviceFeeder needs at least two slots'
         self.slots = [_Slot(i) for i in range(slots)]
         self.event_capacity = event_capacity
         self.columns = columns

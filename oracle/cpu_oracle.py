@@ -35,10 +35,40 @@ def build(force=False):
     return so
 
 
+def use_openmp(threads):
+    """bench.py's cpu_baseline leg: switch to libdvsof_oracle_omp.so (the same
+    source compiled with -fopenmp: loops over images / samples run on
+    ``threads`` cores; results do not depend on the thread count).
+    ``threads`` None: back to the serial checker library."""
+    global _LIB
+    _LIB = None
+    if threads is None:
+        _FLAVOUR[0] = 'libdvsof_oracle.so'
+        return
+    import os
+    os.environ['OMP_NUM_THREADS'] = str(int(threads))
+    _FLAVOUR[0] = 'libdvsof_oracle_omp.so'
+    so = _DIR / _FLAVOUR[0]
+    src = _DIR / 'dvsof_oracle.c'
+    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(['make', '-C', str(_DIR), '-B', _FLAVOUR[0]], check=True,
+                       stdout=subprocess.DEVNULL)
+    lib()
+    try:        # (OMP_NUM_THREADS is read once per process: set the count explicitly)
+        omp = ctypes.CDLL('libgomp.so.1')
+        omp.omp_set_num_threads(int(threads))
+    except OSError:
+        pass
+
+
+_FLAVOUR = ['libdvsof_oracle.so']
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(str(build()))
+        _LIB = ctypes.CDLL(str(build() if _FLAVOUR[0] == 'libdvsof_oracle.so'
+                               else _DIR / _FLAVOUR[0]))
         _LIB.orc_resize_bilinear_ac.argtypes = [c_f, c_f] + [ctypes.c_int] * 5
         _LIB.orc_loss_scale_fwd.argtypes = [c_f, c_f, c_f, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, c_d,

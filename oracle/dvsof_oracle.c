@@ -17,6 +17,9 @@
  * Sums are accumulated in double: the oracle is the "true value" the fp32
  * paths (reference and HIP) are compared against within a stated tolerance.
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -35,11 +38,18 @@ static double drho(double d)
 
 /* F.interpolate(mode='bilinear', align_corners=True), utils/loss.py:20-21.
  * src index = dst * (in-1)/(out-1) in float, taps clamped to the last row/col. */
+/* OpenMP: the pragmas below are active only in libdvsof_oracle_omp.so (make omp:
+ * -fopenmp), the flavour bench.py's cpu_baseline leg times on all host cores.  They split
+ * work over IMAGES / SAMPLES whose outputs are disjoint, so results do not depend on
+ * the thread count; the forward sums are added per sample and then in sample order.
+ * The default library (the checker of tests/ and smoke()) is compiled without -fopenmp:
+ * one thread, the code below as written. */
 void orc_resize_bilinear_ac(const float *src, float *dst, int n, int hin,
                             int win, int hout, int wout)
 {
     const float sh = hout > 1 ? (float)(hin - 1) / (float)(hout - 1) : 0.f;
     const float sw = wout > 1 ? (float)(win - 1) / (float)(wout - 1) : 0.f;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
         const float *s = src + (size_t)i * hin * win;
         float *d = dst + (size_t)i * hout * wout;
@@ -121,11 +131,18 @@ void orc_loss_scale_fwd(const float *prev, const float *next, const float *flow,
     const size_t hw = (size_t)h * w;
     double photo = 0, border = 0;
     double sm[4] = {0, 0, 0, 0};
+#ifdef _OPENMP
+    double (*part)[6] = (double (*)[6])calloc((size_t)N, sizeof(*part));
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
     for (int n = 0; n < N; ++n) {
         const float *U = flow + (size_t)n * 2 * hw, *V = U + hw;
         const float *I0 = prev + (size_t)n * hw, *I1 = next + (size_t)n * hw;
         int64_t cnt = 0;
         double bsum = 0;
+#ifdef _OPENMP      /* this sample's sums; added in sample order below */
+        double photo = 0, sm[4] = {0, 0, 0, 0};
+#endif
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {
                 const size_t p = (size_t)y * w + x;
@@ -151,8 +168,22 @@ void orc_loss_scale_fwd(const float *prev, const float *next, const float *flow,
                 }
             }
         if (oob_count) oob_count[n] = cnt;
+#ifdef _OPENMP
+        part[n][0] = photo;
+        for (int i = 0; i < 4; ++i) part[n][1 + i] = sm[i];
+        part[n][5] = cnt ? bsum / (2.0 * (double)cnt * N) : 0.0;
+#else
         if (cnt) border += bsum / (2.0 * (double)cnt * N); /* :101,:113 */
+#endif
     }
+#ifdef _OPENMP
+    for (int n = 0; n < N; ++n) {
+        photo += part[n][0];
+        for (int i = 0; i < 4; ++i) sm[i] += part[n][1 + i];
+        border += part[n][5];
+    }
+    free(part);
+#endif
     const double c0 = (double)N * 2 * h * (w - 1), c1 = (double)N * 2 * (h - 1) * w,
                  c2 = (double)N * 2 * (h - 1) * (w - 1);
     /* empty crops give 0 (utils/loss.py:29-30) */
@@ -174,6 +205,7 @@ void orc_loss_scale_bwd(const float *prev, const float *next, const float *flow,
     const double c0 = (double)N * 2 * h * (w - 1), c1 = (double)N * 2 * (h - 1) * w,
                  c2 = (double)N * 2 * (h - 1) * (w - 1);
     double *acc = (double *)calloc((size_t)N * 2 * hw, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 1)
     for (int n = 0; n < N; ++n) {
         const float *U = flow + (size_t)n * 2 * hw, *V = U + hw;
         const float *I0 = prev + (size_t)n * hw, *I1 = next + (size_t)n * hw;
@@ -224,6 +256,7 @@ void orc_loss_scale_bwd(const float *prev, const float *next, const float *flow,
                 }
             }
     }
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < (size_t)N * 2 * hw; ++i) grad_flow[i] = (float)acc[i];
     free(acc);
 }
@@ -255,8 +288,18 @@ void orc_voxelize(const int64_t *x, const int64_t *y, const float *t,
 {
     const size_t total = (size_t)B * C * H * W;
     double *acc = (double *)calloc(total, sizeof(double));
+#ifdef _OPENMP  /* thread k owns the samples b with b % T == k (and the events of no sample) */
+#pragma omp parallel
+#endif
     for (int64_t i = 0; i < n; ++i) {
         const int64_t b = sample[i];
+#ifdef _OPENMP
+        {
+            const int T = omp_get_num_threads(), k = omp_get_thread_num();
+            const int owner = (b < 0 || b >= B) ? 0 : (int)(b % T);
+            if (owner != k) continue;
+        }
+#endif
         if (bin0) bin0[i] = -1;
         if (lin0) lin0[i] = -1;
         if (b < 0 || b >= B || x[i] < 0 || x[i] >= W || y[i] < 0 || y[i] >= H) continue;
@@ -274,6 +317,7 @@ void orc_voxelize(const int64_t *x, const int64_t *y, const float *t,
         if (bin0) bin0[i] = c0;
         if (lin0) lin0[i] = (int64_t)base;
     }
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < total; ++i) out[i] = (float)acc[i];
     free(acc);
 }

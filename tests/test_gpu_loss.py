@@ -160,11 +160,14 @@ def test_baseline_size_properties():
     for k in range(4):
         assert abs(float(t[0][k]) - 1e-6 ** 0.45) < 1e-8
         assert float(t[2][k]) == 0.0
-    # a sample of the full-size result against the oracle (scale 0 and 1)
-    o_terms, _, _ = orc.losses(flows_np[:2], c['flow_ts'], c['flow_sample_idx'],
-                               c['images'], c['timestamps'], c['sample_idx'],
-                               with_grad=False)
-    np.testing.assert_allclose(ta[:, :2], o_terms, rtol=TERM_RTOL)
+    # the full-size result against the oracle: all four scales, terms AND flow gradients
+    o_terms, o_loss, o_grads = orc.losses(flows_np, c['flow_ts'], c['flow_sample_idx'],
+                                          c['images'], c['timestamps'], c['sample_idx'])
+    np.testing.assert_allclose(ta, o_terms, rtol=TERM_RTOL)
+    assert abs(la - o_loss) <= TERM_RTOL * abs(o_loss)
+    for a, o in zip(ga, o_grads):       # field norm
+        assert np.linalg.norm(a - o) <= 1e-3 * np.linalg.norm(o), \
+            np.linalg.norm(a - o) / np.linalg.norm(o)
 
 
 @pytest.mark.parametrize('src,shapes', [
