@@ -571,9 +571,15 @@ static int wp_channel_tile(const WGradParams &P)
     return 32;
 }
 
+// wgrad_min.hip: the nine-product form of the same gradient (exact f32)
+bool wgrad_min_ok(const WGradParams &P);
+int wgrad_min_splits(const WGradParams &P);
+int wgrad_min_launch(WGradParams &P, hipStream_t st);
+
 // K splits for this kernel: enough workgroups for two per CU
 int wgrad_patch_splits(const WGradParams &P)
 {
+    if (wp_f32(P) && wgrad_min_ok(P)) return wgrad_min_splits(P);
     const int CT = wp_channel_tile(P);
     long long tiles = (long long)(P.Cout / 32);
     long long ct = 0;
@@ -643,6 +649,7 @@ static int wp_launch_f32(WGradParams &P, hipStream_t st)
 int wgrad_patch_launch(const WGradParams &P0, hipStream_t st)
 {
     WGradParams P = P0;
+    if (wp_f32(P) && wgrad_min_ok(P)) return wgrad_min_launch(P, st);
     const int ct = wp_channel_tile(P);
     if (wp_f32(P)) return ct == 64 ? wp_launch_f32<64>(P, st) : wp_launch_f32<32>(P, st);
     return ct == 64 ? wp_launch<64>(P, st) : wp_launch<32>(P, st);
