@@ -222,10 +222,11 @@ def prepare(desc, weight, want_dgrad, phase_weights=None, want16=False):
     if make_fwd or want_dgrad:
         # Winograd layer: both forms come from the raw weights
         wino = nscratch > 0
-        # sub-pixel layer, dgrad only: weight = NULL, w_fwd = the phase kernels
-        wp = None if (dg_only and nf != raw and not wino) else weight.data_ptr()
+        # dgrad only: w_fwd = NULL, the data-gradient form comes from the raw weights (the
+        # forward form of a sub-pixel layer may be the nine-product one: csrc/fwd_min.hip)
+        wp = weight.data_ptr()
         fp = w_fwd.data_ptr() if (nf != raw) else None
-        if wino and dg_only:
+        if dg_only:
             fp = None
         if want16 and not wino:
             dev = weight.device

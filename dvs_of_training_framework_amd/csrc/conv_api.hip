@@ -42,6 +42,10 @@ void conv_note_patch(int kind) { t_last_patch[kind] = 1; }
 // weights in registers)
 bool fwd_patch_eligible(const GConvParams &P);
 int fwd_patch_launch(const GConvParams &P, hipStream_t st);
+// fwd_min.hip: the nine-product form of `nearest-up2 -> conv3x3` (exact f32)
+bool min9_shape_ok(int mfma, int nsrc, const int *C, const int *nhwc, int Cout, int H, int W);
+int min9_prepare_fwd(const float *w, float *wt, int Cout, int Ctot, hipStream_t st);
+int fwd_min_launch(const GConvParams &P, hipStream_t st);
 
 namespace {
 
@@ -104,6 +108,19 @@ bool desc_ok(const dvsof_conv_desc_t *d, int &Ctot, int &Ho, int &Wo)
 bool is_subpixel(const dvsof_conv_desc_t *d)
 {   // up2 + 3x3/pad1/stride1 == four 2x2 phase convolutions on the low-res input
     return d->upsample == 1 && d->ksize == 3 && d->pad == 1 && d->stride == 1;
+}
+
+// ... and of those the ones whose FORWARD runs the nine-product minimal algorithm
+// (fwd_min.hip): the prepared forward form is then Wt[9][Cout][Ctot] = G w G^T
+bool is_min9(const dvsof_conv_desc_t *d)
+{
+    if (!is_subpixel(d)) return false;
+    int C[3] = {0, 0, 0}, nhwc[3] = {0, 0, 0};
+    for (int i = 0; i < d->nsrc && i < 3; ++i) {
+        C[i] = d->src[i].C;
+        nhwc[i] = d->src[i].layout == DVSOF_NHWC;
+    }
+    return min9_shape_ok(d->mfma, d->nsrc, C, nhwc, d->Cout, d->H, d->W);
 }
 
 // zero-insertion 2x + 3x3/pad 1 = transposed convolution with stride 2:
@@ -187,6 +204,45 @@ __global__ __launch_bounds__(256) void subpixel_dgrad_weights_kernel(const float
     for (int r = ly; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + lx;
         tile[r][lx] = (co < Cout && ci < Ctot) ? in[(size_t)co * 4 * Ctot + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + lx;
+        if (ci < Ctot && co < Cout) {
+            const size_t o = ((size_t)ci * 16 + z) * Cout + co;
+            wd[o] = tile[lx][r];
+            if (wd16) wd16[o] = bf16_bits(tile[lx][r]);
+        }
+    }
+}
+
+// The same Wd straight from the RAW weights w[co][3][3][ci] (a caller that no longer holds
+// the phase kernels, or whose forward form is another one: fwd_min.hip): per axis tap t of
+// the 4x4 kernel sums the raw taps {2}, {1,2}, {0,1}, {0} -- the same additions in the same
+// order as subpixel_fwd_weights_kernel, so both routes give the same bits.
+__global__ __launch_bounds__(256) void subpixel_dgrad_weights_raw_kernel(const float *__restrict__ w,
+                                                                         float *__restrict__ wd,
+                                                                         int Cout, int Ctot,
+                                                                         unsigned short *__restrict__ wd16)
+{
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, ty = z >> 2, tx = z & 3;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + lx;
+        float v = 0.f;
+        if (co < Cout && ci < Ctot) {
+            const float *k = w + (size_t)co * 9 * Ctot + ci;
+            // (rows are summed FIRST in subpixel_fwd_weights_kernel, then columns)
+            auto col = [&](int kx) -> float {
+                const float *kc = k + (size_t)kx * Ctot;
+                return ty == 0 ? kc[6 * Ctot] : ty == 1 ? kc[3 * Ctot] + kc[6 * Ctot]
+                     : ty == 2 ? kc[0] + kc[3 * Ctot] : kc[0];
+            };
+            v = tx == 0 ? col(2) : tx == 1 ? col(1) + col(2) : tx == 2 ? col(0) + col(1) : col(0);
+        }
+        tile[r][lx] = v;
     }
     __syncthreads();
     for (int r = ly; r < 32; r += 8) {
@@ -741,6 +797,10 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     }
     if (is_wino(d))   // `weight` is the prepared U[16][Cout][Ctot]
         return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
+    if (is_min9(d)) {   // `weight` is the prepared Wt[9][Cout][Ctot]
+        t_last_patch[0] = 2;
+        return fwd_min_launch(P, as_stream(stream));
+    }
     if (is_subpixel(d) && fwd_patch_eligible(P)) {  // finest decoder stage: fwd_patch.hip
         t_last_patch[0] = 1;
         return fwd_patch_launch(P, as_stream(stream));
@@ -1007,10 +1067,32 @@ int dvsof_conv2d_prepare16(const dvsof_conv_desc_t *d, const float *weight, floa
     unsigned short *w_fwd16 = (unsigned short *)w_fwd16_, *w_dgrad16 = (unsigned short *)w_dgrad16_;
     if (w_dgrad16 && !w_dgrad) return DVSOF_EINVAL;
     if (is_subpixel(d)) {
-        if (!w_fwd) return DVSOF_EINVAL;
+        if (!w_fwd && !weight) return DVSOF_EINVAL;
         // weight == NULL: w_fwd already holds the phase kernels (made by an
         // earlier call); only the data-gradient form is derived from it
         if (!weight && !w_dgrad) return DVSOF_EINVAL;
+        if (is_min9(d) || (weight && !w_fwd)) {
+            // both forms from the RAW weights: forward Wt[9][Cout][Ctot] (fwd_min.hip) or the
+            // phase kernels; the data gradient's 4x4 stride-2 form Wd
+            if (!weight || (!w_fwd && !w_dgrad)) return DVSOF_EINVAL;
+            if (w_fwd && is_min9(d)) {
+                if (w_fwd16) return DVSOF_EINVAL;
+                const int rc = min9_prepare_fwd(weight, w_fwd, d->Cout, Ctot, st);
+                if (rc) return rc;
+            } else if (w_fwd) {
+                const size_t n = (size_t)d->Cout * Ctot;
+                hipLaunchKernelGGL(subpixel_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)),
+                                   dim3(256), 0, st, weight, w_fwd, d->Cout, Ctot, w_fwd16);
+                DVSOF_LAUNCH_CHECK();
+            }
+            if (w_dgrad) {
+                dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);
+                hipLaunchKernelGGL(subpixel_dgrad_weights_raw_kernel, grid, dim3(256), 0, st, weight, w_dgrad,
+                                   d->Cout, Ctot, w_dgrad16);
+                DVSOF_LAUNCH_CHECK();
+            }
+            return DVSOF_OK;
+        }
         if (weight) {
             const size_t n = (size_t)d->Cout * Ctot;
             hipLaunchKernelGGL(subpixel_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)),

@@ -75,6 +75,15 @@ CASES = [
     dict(B=1, H=2, W=16, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
     dict(B=3, H=10, W=48, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True, act='mish'),
     dict(B=2, H=64, W=64, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
+    # decoder stages whose exact-f32 forward is the nine-product form (csrc/fwd_min.hip: 4 | H,
+    # 16 | W, two NHWC members of multiples of 32 channels): 4-row blocks with the K split over
+    # the waves / 8-row blocks, members of different widths, Mish with its pre-activation copy,
+    # blocks on every border of the frame, the coarsest benchmark stage's channel counts
+    dict(B=2, H=12, W=32, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True, act='mish'),
+    dict(B=1, H=8, W=16, src=[(32, 'nhwc'), (96, 'nhwc')], Cout=64, up=True),
+    dict(B=3, H=24, W=48, src=[(64, 'nhwc'), (32, 'nhwc')], Cout=96, up=True, act='none'),
+    dict(B=8, H=16, W=16, src=[(256, 'nhwc'), (256, 'nhwc')], Cout=128, up=True),
+    dict(B=16, H=16, W=32, src=[(32, 'nhwc'), (32, 'nhwc')], Cout=32, up=True),
 ]
 
 
@@ -193,6 +202,15 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     dict(B=1, H=2, W=16, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
     dict(B=3, H=10, W=48, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True, act='mish'),
     dict(B=2, H=64, W=64, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
+    # decoder stages whose exact-f32 forward is the nine-product form (csrc/fwd_min.hip: 4 | H,
+    # 16 | W, two NHWC members of multiples of 32 channels): 4-row blocks with the K split over
+    # the waves / 8-row blocks, members of different widths, Mish with its pre-activation copy,
+    # blocks on every border of the frame, the coarsest benchmark stage's channel counts
+    dict(B=2, H=12, W=32, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True, act='mish'),
+    dict(B=1, H=8, W=16, src=[(32, 'nhwc'), (96, 'nhwc')], Cout=64, up=True),
+    dict(B=3, H=24, W=48, src=[(64, 'nhwc'), (32, 'nhwc')], Cout=96, up=True, act='none'),
+    dict(B=8, H=16, W=16, src=[(256, 'nhwc'), (256, 'nhwc')], Cout=128, up=True),
+    dict(B=16, H=16, W=32, src=[(32, 'nhwc'), (32, 'nhwc')], Cout=32, up=True),
 ])
 def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
     """mfma mode 3: the vector members' weight gradient streams the bf16 TWINS
