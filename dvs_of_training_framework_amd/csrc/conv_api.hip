@@ -46,6 +46,10 @@ int fwd_patch_launch(const GConvParams &P, hipStream_t st);
 bool min9_shape_ok(int mfma, int nsrc, const int *C, const int *nhwc, int Cout, int H, int W);
 int min9_prepare_fwd(const float *w, float *wt, int Cout, int Ctot, hipStream_t st);
 int fwd_min_launch(const GConvParams &P, hipStream_t st);
+// dgrad_min.hip: its data gradient, nine products too (prepared form W'[9][Ctot][Cout])
+bool min9_dgrad_shape_ok(const int *C, int Cout, int H);
+int min9_prepare_dgrad(const float *w, float *wq, int Cout, int Ctot, hipStream_t st);
+int dgrad_min_launch(const GConvParams &P, hipStream_t st);
 
 namespace {
 
@@ -121,6 +125,13 @@ bool is_min9(const dvsof_conv_desc_t *d)
         nhwc[i] = d->src[i].layout == DVSOF_NHWC;
     }
     return min9_shape_ok(d->mfma, d->nsrc, C, nhwc, d->Cout, d->H, d->W);
+}
+
+bool is_min9_dgrad(const dvsof_conv_desc_t *d)
+{
+    if (!is_min9(d)) return false;
+    const int C[2] = {d->src[0].C, d->src[1].C};
+    return min9_dgrad_shape_ok(C, d->Cout, d->H);
 }
 
 // zero-insertion 2x + 3x3/pad 1 = transposed convolution with stride 2:
@@ -906,6 +917,8 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         P.quad = 0;
     }
     P.M = d->B * P.Ho * P.Wo;
+    if (is_min9_dgrad(d))   // weight_t is the prepared W'[9][Ctot][Cout]
+        return dgrad_min_launch(P, as_stream(stream));
     if (is_wino(d))   // weight_t is the prepared U'[16][Ctot][Cout]
         return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
     return gconv_launch(P, 0, as_stream(stream));
@@ -1084,6 +1097,10 @@ int dvsof_conv2d_prepare16(const dvsof_conv_desc_t *d, const float *weight, floa
                 hipLaunchKernelGGL(subpixel_fwd_weights_kernel, dim3((unsigned)((n + 255) / 256)),
                                    dim3(256), 0, st, weight, w_fwd, d->Cout, Ctot, w_fwd16);
                 DVSOF_LAUNCH_CHECK();
+            }
+            if (w_dgrad && is_min9_dgrad(d)) {
+                if (w_dgrad16) return DVSOF_EINVAL;
+                return min9_prepare_dgrad(weight, w_dgrad, d->Cout, Ctot, st);
             }
             if (w_dgrad) {
                 dim3 grid((Ctot + 31) / 32, (d->Cout + 31) / 32, 16);

@@ -1,0 +1,307 @@
+// Data gradient of a 2x up-sampling decoder stage with NINE products per
+// low-resolution pixel instead of sixteen (exact f32, v_mfma_f32_32x32x2_f32).
+//
+// The adjoint of `nearest-up2 -> conv3x3(pad 1)` (EV_FlowNet decoder; reference
+// call site utils/training.py:158 through the absent EV_FlowNet.net).  Per axis
+// the forward is y[2i] = a x[i-1] + b x[i], y[2i+1] = c x[i] + d x[i+1] with
+// a = w0, b = w1 + w2, c = w0 + w1 = a + b - d, d = w2 (csrc/wgrad_min.hip), so
+//     gx[i] = b g[2i] + c g[2i+1] + a g[2i+2] + d g[2i-1]
+//           = b (g[2i] + g[2i+1]) + a (g[2i+1] + g[2i+2]) + d (g[2i-1] - g[2i+1])
+// three products instead of four, all of them gathered AT the output pixel (the
+// sub-pixel form's 4x4 stride-2 kernel has sixteen taps in 2-D, this has nine):
+//     gx[i][j] = sum_{p,q} W'[p][q]^T S[p][q][i][j]
+//     S[p][q]  = R_p(rows) C_q(columns) of the 4 x 4 fine-resolution window
+//                g[2i-1 .. 2i+2][2j-1 .. 2j+2], R = C = (g1 + g2, g2 + g3, g0 - g2)
+//     W'       = G' w G'^T,  G' = [[0,1,1],[1,0,0],[0,0,1]]
+// g is zero outside the frame.  All nine components accumulate into ONE
+// accumulator per output tile (a K concatenation): no output transform.
+//
+// Kernel: a workgroup of 8 waves owns 64 input channels x a block of 8 rows x
+// 16 columns of low-resolution pixels and walks the output channels (K) in
+// chunks of 16: per chunk the 18 x 34 fine-resolution patch of the gradient
+// and the nine 64 x 16 weight tiles go L2 -> LDS by LDS-DMA (double buffered).
+// A wave is (pixel tile of 2 rows x 16 pixels, K half): per group of 4 channels
+// it reads the 16 window fragments (ds_read_b64: two K steps each), makes the
+// nine S pairs with 21 packed additions -- shared by its TWO 32-channel output
+// tiles -- reads 18 weight fragments and issues 36 matrix instructions.  LDS
+// images as in fwd_min.hip (rows dealt to arrays by residue, arrays padded by
+// 16 bytes: no swizzle, the channel group is an immediate offset); the fine
+// patch is cut into even and odd columns because a fragment read walks it with
+// stride 2.  Epilogue: the two K halves meet in LDS, transposed to pixel-major;
+// 8 lanes store one pixel's 128 bytes into the member (x or skip) the channel
+// tile belongs to: + addend(s), x act'(actsrc) as the shared epilogue does.
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr unsigned DM_OOB = 0x80000000u;
+constexpr int DM_NT = 512;
+constexpr int DM_NR = 8;                         // low-resolution rows per block (x 16 columns)
+constexpr int DM_AARR = 9 * 1024 + 16;           // weight array: 144 rows of 64 B (9 components x 16)
+constexpr int DM_AP = 4 * 9;                     // weight pieces
+constexpr int DM_PR = 17;                        // column pairs per fine row (34 columns)
+constexpr int DM_NPAIR = (2 * DM_NR + 2) * DM_PR;    // 306
+constexpr int DM_BPA = 5;                        // pieces per patch array (77 rows of 64 B)
+constexpr int DM_BARR = DM_BPA * 1024 + 16;
+constexpr int DM_BOFF = 4 * DM_AARR;
+constexpr int DM_BP = 8 * DM_BPA;                // 2 planes x 4 arrays
+constexpr int DM_NPIECE = DM_AP + DM_BP;         // 76
+constexpr int DM_LPW = (DM_NPIECE + 7) / 8;      // 10 rounds; the last one is partial
+constexpr int DM_STAGE = ((DM_BOFF + 8 * DM_BARR + 1023) / 1024) * 1024;
+constexpr int DM_LDS = 2 * DM_STAGE;
+
+// W'[3 p + q][ci][co] = sum_{k,l} G'[p][k] G'[q][l] w[co][k][l][ci]: rows of G' pick the raw taps
+// {1,2}, {0}, {2}
+__global__ __launch_bounds__(256) void min9_dgrad_weights_kernel(const float *__restrict__ w, float *__restrict__ wq,
+                                                                 int Cout, int Ctot)
+{
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, p = z / 3, q = z - 3 * p;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + lx;
+        float v = 0.f;
+        if (co < Cout && ci < Ctot) {
+            const float *k = w + (size_t)co * 9 * Ctot + ci;
+            auto col = [&](int kx) -> float {   // rows first
+                const float *kc = k + (size_t)kx * Ctot;
+                return p == 0 ? kc[3 * Ctot] + kc[6 * Ctot] : p == 1 ? kc[0] : kc[6 * Ctot];
+            };
+            v = q == 0 ? col(1) + col(2) : q == 1 ? col(0) : col(2);
+        }
+        tile[r][lx] = v;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + lx;
+        if (ci < Ctot && co < Cout) wq[((size_t)z * Ctot + ci) * Cout + co] = tile[lx][r];
+    }
+}
+
+__global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams P)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pt = wave & 3, ks = wave >> 2;
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int H = P.Ho, W = P.Wo;                   // low-resolution frame (the outputs)
+    const int FH = 2 * H, FW = 2 * W;               // fine frame (the gradient)
+    const int Cout = P.Cin_tot, Ctot = P.N;         // K = output channels of the layer
+    const int nbx = W / 16, nby = H / DM_NR;
+
+    unsigned wg = blockIdx.x;
+    {
+        const unsigned total = gridDim.x, x = wg & 7u, q = total >> 3, r = total & 7u;
+        wg = x * q + min(x, r) + (wg >> 3);
+    }
+    const int nct = Ctot / 64;
+    const int ct64 = (int)(wg % (unsigned)nct), blk = (int)(wg / (unsigned)nct);
+    const int ci0 = 64 * ct64;
+    const int bx = blk % nbx, by = (blk / nbx) % nby, b = blk / (nbx * nby);
+    const int oy = DM_NR * by, ox = 16 * bx;
+
+    // ---- DMA roles: piece p = wave + 8 i; lane l lands at piece base + 16 l = row l >> 2, quarter l & 3
+    const GSrc &GS = P.src[0];
+    unsigned off[DM_LPW];
+#pragma unroll
+    for (int i = 0; i < DM_LPW; ++i) {
+        const int p = wave + 8 * i;
+        off[i] = DM_OOB;
+        if (p < DM_AP) {
+            const int m = p / 9, pp = p - 9 * m;
+            const int j = 16 * pp + (lane >> 2);        // row within array m: (component, ci >> 2)
+            const int c = j >> 4, r = 4 * (j & 15) + m;
+            off[i] = (unsigned)((((size_t)c * Ctot + ci0 + r) * Cout + 4 * (lane & 3)) * 4);
+        } else if (p < DM_NPIECE) {
+            const int pb = p - DM_AP;
+            const int arr = pb / DM_BPA, pp = pb - DM_BPA * arr;
+            const int pr = 4 * (16 * pp + (lane >> 2)) + (arr & 3);     // column pair
+            if (pr < DM_NPAIR) {
+                const int n = 2 * pr + (arr >> 2);      // fine slot: row n / 34, column n % 34
+                const int fr = n / 34, fc = n - 34 * fr;
+                // (the resource's base is shifted by (-1, -1): offsets stay non-negative)
+                if (((unsigned)(2 * oy + fr - 1) < (unsigned)FH) & ((unsigned)(2 * ox + fc - 1) < (unsigned)FW))
+                    off[i] = (unsigned)((fr * GS.sy + fc * GS.sx + 4 * (lane & 3)) * 4);
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void *)P.W, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(GS.p - ((long long)GS.sy + GS.sx)), 0, 0x7fffffff, 0x00020000);
+    const int gbase = __builtin_amdgcn_readfirstlane(
+        (int)(((long long)b * GS.sb + (long long)(2 * oy) * GS.sy + (long long)(2 * ox) * GS.sx) * 4));
+    const int nchunks = Cout / 16;
+
+    auto issue = [&](int stage_idx, int ch) {
+        unsigned char *st = smem + stage_idx * DM_STAGE;
+#pragma unroll
+        for (int i = 0; i < DM_LPW; ++i) {
+            const int p = wave + 8 * i;
+            if (p < DM_AP) {
+                const int m = p / 9, pp = p - 9 * m;
+                __attribute__((address_space(3))) void *dst =
+                    (__attribute__((address_space(3))) void *)(st + m * DM_AARR + pp * 1024);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, off[i], ch * 64, 0, 0);
+            } else if (p < DM_NPIECE) {
+                const int pb = p - DM_AP;
+                const int arr = pb / DM_BPA, pp = pb - DM_BPA * arr;
+                __attribute__((address_space(3))) void *dst =
+                    (__attribute__((address_space(3))) void *)(st + DM_BOFF + arr * DM_BARR + pp * 1024);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, off[i], gbase + ch * 64, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addresses (relative to a stage)
+    // A: weight row (component c, ci r = 32 ct + lrow) -> array r & 3, row 16 c + (r >> 2)
+    const int abase = (lrow & 3) * DM_AARR + (lrow >> 2) * 64 + 8 * lh;
+    // B: window element (u, v) of pixel (li, lj) of this wave's tile: fine slot
+    // n = (2 (2 pt + li) + u) 34 + 2 lj + v -> plane v & 1, pair (n >> 1) = (...) 17 + lj + (v >> 1)
+    int bb[4][2];
+    {
+        const int li = lrow >> 4, lj = lrow & 15;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pr = (2 * (2 * pt + li) + u) * DM_PR + lj + h;
+                bb[u][h] = DM_BOFF + (pr & 3) * DM_BARR + (pr >> 2) * 64 + 8 * lh;
+            }
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto compute = [&](int u_) {
+        const unsigned char *st = smem + u_ * DM_STAGE;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int kg = 2 * ks + gi;                 // group of 4 output channels (16 bytes of a row)
+            f32x2 g[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    g[u][v] = *(const f32x2 *)(st + bb[u][v >> 1] + (v & 1) * (4 * DM_BARR) + 16 * kg);
+            // columns, then rows
+            f32x2 cc[4][3], s[9];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cc[u][0] = g[u][1] + g[u][2];
+                cc[u][1] = g[u][2] + g[u][3];
+                cc[u][2] = g[u][0] - g[u][2];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                s[q] = cc[1][q] + cc[2][q];
+                s[3 + q] = cc[2][q] + cc[3][q];
+                s[6 + q] = cc[0][q] - cc[2][q];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    const f32x2 a = *(const f32x2 *)(st + abase + (16 * c + 8 * t) * 64 + 16 * kg);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], s[c][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], s[c][1], acc[t], 0, 0, 0);
+                }
+        }
+    };
+
+    issue(0, 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ch + 1 < nchunks) issue((ch + 1) & 1, ch + 1);
+        compute(ch & 1);
+    }
+
+    // ---- epilogue: [wave][tile][pixel 32][ci 32] rows of 128 bytes, chunks XOR-swizzled by pixel & 7
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        unsigned char *xt_ = smem + (wave * 2 + t) * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            *(f32x4 *)(xt_ + lrow * 128 + (((2 * g + lh) ^ (lrow & 7)) << 4)) = v;
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    // this wave finishes channel tile t = ks of its pixel tile: which member, where in it
+    const int cit = ci0 + 32 * ks;
+    const int c_first = P.dst[0].C;
+    const int sel = cit >= c_first ? 1 : 0;
+    const GDst &D = P.dst[sel];
+    const int cm = cit - (sel ? c_first : 0);
+    const int ecq = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int px = 8 * it + (lane >> 3);
+        const int xo = px * 128 + ((ecq ^ (px & 7)) << 4);
+        f32x4 v = *(const f32x4 *)(smem + (pt * 2 + ks) * 4096 + xo) +
+                  *(const f32x4 *)(smem + ((pt + 4) * 2 + ks) * 4096 + xo);
+        const int yy = oy + 2 * pt + (px >> 4), xx = ox + (px & 15);
+        const long long o = (long long)b * D.sb + (long long)yy * D.sy + (long long)xx * D.sx + cm + 4 * ecq;
+        if (D.addend) v += *(const f32x4 *)(D.addend + o);
+        if (D.addend2) v += *(const f32x4 *)(D.addend2 + o);
+        if (D.actsrc) {
+            const f32x4 a = *(const f32x4 *)(D.actsrc + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_bwd(a[e], P.bwd_act);
+        }
+        *(f32x4 *)(D.p + o) = v;
+    }
+#endif
+}
+
+}  // namespace
+
+// the descriptor's shape beyond fwd_min's test: 64 | every member, 8 | H
+// (DVSOF_NO_DGRAD_MIN=1: the 4x4 stride-2 form on gconv2)
+bool min9_dgrad_shape_ok(const int *C, int Cout, int H)
+{
+    static const bool off = getenv("DVSOF_NO_DGRAD_MIN") != nullptr;
+    return !off && (C[0] & 63) == 0 && (C[1] & 63) == 0 && (H % DM_NR) == 0 && (Cout & 15) == 0;
+}
+
+int min9_prepare_dgrad(const float *w, float *wq, int Cout, int Ctot, hipStream_t st)
+{
+    dim3 grid((Ctot + 31) / 32, (Cout + 31) / 32, 9);
+    hipLaunchKernelGGL(min9_dgrad_weights_kernel, grid, dim3(256), 0, st, w, wq, Cout, Ctot);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
+// P as dvsof_conv2d_dgrad fills it for a sub-pixel layer (P.W = W'[9][Ctot][Cout] here)
+int dgrad_min_launch(const GConvParams &P, hipStream_t st)
+{
+    const GSrc &S = P.src[0];
+    if (!S.p || (reinterpret_cast<uintptr_t>(S.p) & 15) || ((S.sb | S.sy | S.sx) & 3) || S.sc != 1) return DVSOF_EINVAL;
+    if (P.ndst != 2 || (reinterpret_cast<uintptr_t>(P.W) & 15)) return DVSOF_EINVAL;
+    for (int i = 0; i < 2; ++i) {
+        const GDst &D = P.dst[i];
+        if (!D.p || D.sc != 1 || ((D.sb | D.sy | D.sx) & 3)) return DVSOF_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(D.p) | reinterpret_cast<uintptr_t>(D.addend) |
+             reinterpret_cast<uintptr_t>(D.addend2) | reinterpret_cast<uintptr_t>(D.actsrc)) & 15)
+            return DVSOF_EINVAL;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)dgrad_min_f32_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS));
+        attr_set = true;
+    }
+    const long long grid = (long long)P.B * (P.Ho / DM_NR) * (P.Wo / 16) * (P.N / 64);
+    hipLaunchKernelGGL(dgrad_min_f32_kernel, dim3((unsigned)grid), dim3(DM_NT), DM_LDS, st, P);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}

@@ -448,6 +448,27 @@ def test_dgrad_epilogue_addends_and_act(case):
     close(from_nhwc(buf), want)
 
 
+def test_decoder_dgrad_nine_product_form_epilogue():
+    """csrc/dgrad_min.hip (two members of 64 | C, 8 | H): the gradient lands in
+    the member its channel tile belongs to; addends and act' on one member only
+    (the decoder's first stage: x = the last residual output)."""
+    from dvs_of_training_framework_amd import conv as C
+    case = dict(B=2, H=16, W=32, src=[(128, 'nhwc'), (64, 'nhwc')], Cout=48 + 16, up=True)
+    C, xs, w, b, desc, act, o = build(case, seed=5)
+    xs = [x.requires_grad_(True) for x in xs]
+    _, z_ref = torch_fwd(xs, w, b, o, act, C)
+    gz = torch.randn(z_ref.shape)
+    z_ref.backward(gz)
+    a1, a2, ysrc = (torch.randn(xs[0].shape) for _ in range(3))
+    want0 = (xs[0].grad + a1 + a2) * (ysrc > 0).float()
+    bufs = [torch.empty(2, 16, 32, c, device='cuda') for c, _ in case['src']]
+    _, wt = C.prepare(desc, wphys(w), True)
+    C.conv_dgrad(desc, wt, nhwc(gz), [dict(p=bufs[0], addend=nhwc(a1), addend2=nhwc(a2),
+                                           actsrc=nhwc(ysrc)), dict(p=bufs[1])], C.ACT_RELU)
+    close(from_nhwc(bufs[0]), want0)
+    close(from_nhwc(bufs[1]), xs[1].grad)
+
+
 @pytest.mark.parametrize('Cc,act', [(32, 'relu'), (256, 'relu'), (64, 'mish')])
 def test_flow_head(Cc, act):
     from dvs_of_training_framework_amd import conv as C
