@@ -131,8 +131,12 @@ TILE_SHAPES = {
 }
 
 
-def kernel_name(family, tile, gen, wino=0, patch=0, dtype='f32'):
+def kernel_name(family, tile, gen, wino=0, patch=0, dtype='f32', kind=0):
     """Name as rocprofv3 reports it (kernel template + tile shape)."""
+    if patch == 2:  # csrc/fwd_min.hip, dgrad_min.hip, wgrad_min.hip: nine products per low-res pixel
+        return {0: 'fwd_min_f32_kernel (9-product up2+conv3x3, 32 cout x NR x 16 px blocks)',
+                1: 'dgrad_min_f32_kernel (9-product, 64 cin x 8 x 16 px blocks)',
+                2: 'wgrad_min_f32_kernel (9-product, 32 cout x 64 cin) + slab_reduce'}[kind]
     if patch:   # csrc/fwd_patch.hip, csrc/wgrad_patch.hip: patch-resident decoder kernels
         k = 'f32' if dtype == 'f32' else 'twins'
         return (f'fwd_patch_{k}_kernel 2x16 px blocks' if family == 'gconv'
@@ -318,15 +322,16 @@ def conv_flops(desc, kind):
     return 2.0 * desc.B * ho * wo * desc.Cout * ctot * desc.ksize ** 2
 
 
-def executed_flops(desc, kind):
+def executed_flops(desc, kind, patch=0):
     """FLOPs the MFMA kernels actually issue: the sub-pixel decomposition of
-    upsample+3x3 runs 16 instead of 36 tap-products (the phased stride-2 data
-    gradient runs exactly its 9: phase (py,px) has (1+py)(1+px) taps)."""
+    upsample+3x3 runs 16 instead of 36 tap-products, its minimal form (patch ==
+    2: csrc/*_min.hip) 9 (the phased stride-2 data gradient runs exactly its 9:
+    phase (py,px) has (1+py)(1+px) taps)."""
     import ctypes
     from dvs_of_training_framework_amd import conv as C
     f = conv_flops(desc, kind)
     if desc.upsample and desc.ksize == 3 and desc.pad == 1:
-        return f * 16.0 / 36.0
+        return f * (9.0 if patch == 2 else 16.0) / 36.0
     m = C._lib.lib().dvsof_conv2d_winograd_tile(ctypes.byref(desc), kind)
     if m:   # (m+2)^2 products per m x m outputs instead of 9 m^2
         return f * (m + 2) ** 2 / (9.0 * m * m)
@@ -370,9 +375,9 @@ def measure_roofline(h, step_ms, steps=3, light=False):
             e0.record()
             out = fn(desc, *args, **kw)
             e1.record()
-            patch = lib.dvsof_conv2d_last_patch(kind) if kind != 1 else 0
-            records.append((kernel_name(family, tile, gen, wino, patch, h.a.dtype), conv_flops(desc, kind),
-                            e0, e1, executed_flops(desc, kind)))
+            patch = lib.dvsof_conv2d_last_patch(kind)
+            records.append((kernel_name(family, tile, gen, wino, patch, h.a.dtype, kind), conv_flops(desc, kind),
+                            e0, e1, executed_flops(desc, kind, patch)))
             return out
         return inner
 

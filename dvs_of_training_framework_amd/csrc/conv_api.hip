@@ -36,7 +36,7 @@ int first_wgrad_launch(const float *x, int B, int C, int H, int W, const float *
 
 // set by the launches below / read by dvsof_conv2d_last_patch (profiling tools)
 static thread_local int t_last_patch[3] = {0, 0, 0};
-void conv_note_patch(int kind) { t_last_patch[kind] = 1; }
+void conv_note_patch(int kind, int what) { t_last_patch[kind] = what; }
 
 // fwd_patch.hip: forward of the finest decoder stage in the bf16-twins mode (patch in LDS,
 // weights in registers)
@@ -917,8 +917,11 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         P.quad = 0;
     }
     P.M = d->B * P.Ho * P.Wo;
-    if (is_min9_dgrad(d))   // weight_t is the prepared W'[9][Ctot][Cout]
+    t_last_patch[1] = 0;
+    if (is_min9_dgrad(d)) {  // weight_t is the prepared W'[9][Ctot][Cout]
+        t_last_patch[1] = 2;
         return dgrad_min_launch(P, as_stream(stream));
+    }
     if (is_wino(d))   // weight_t is the prepared U'[16][Ctot][Cout]
         return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
     return gconv_launch(P, 0, as_stream(stream));
@@ -1202,7 +1205,7 @@ int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *d, int kind)
 
 int dvsof_conv2d_last_patch(int kind)
 {
-    return (kind == 0 || kind == 2) ? t_last_patch[kind] : 0;
+    return (kind >= 0 && kind <= 2) ? t_last_patch[kind] : 0;
 }
 
 int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)

@@ -243,6 +243,10 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
         compute(ch & 1);
     }
 
+    // (Measured and not kept, batch 8: the next group's 18 fragment reads issued ahead of this
+    // group's matrix instructions -- register double buffering, with and without
+    // sched_group_barrier ordering: 105-136 / 108-164 us per stage against 101-119; the two
+    // waves of a SIMD already cover each other's read -> subtract phases.)
     // ---- epilogue.  Phase tiles (a, b) = sums of four components; [pixel 32][co 32] rows of
     // 128 bytes per (wave, phase), 16-byte chunks XOR-swizzled by pixel & 7
     __builtin_amdgcn_s_barrier();       // every wave is done with the stages

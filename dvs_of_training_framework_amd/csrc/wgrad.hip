@@ -895,7 +895,8 @@ bool wgrad_patch_shape_ok(const WGradParams &P);
 bool wgrad_patch_eligible(const WGradParams &P);
 int wgrad_patch_splits(const WGradParams &P);
 int wgrad_patch_launch(const WGradParams &P, hipStream_t st);
-void conv_note_patch(int kind);     // conv_api.hip
+void conv_note_patch(int kind, int what);     // conv_api.hip
+bool wgrad_min_ok(const WGradParams &P);  // wgrad_min.hip
 
 // Number of K splits used for this problem (deterministic in the shape).
 int wgrad_splits(const WGradParams &P0, int *tile_out)
@@ -960,7 +961,7 @@ int wgrad_launch(WGradParams P, float *dW, float *dbias, float *ws, size_t ws_fl
             }
             // (flat members on the v1 tiles would write phase-form columns into the same slabs)
             if (!direct && wgrad_patch_eligible(P) && (flat_valu || nflat == 0)) {
-                conv_note_patch(2);
+                conv_note_patch(2, (!P.twins && P.mfma_bf16 == 0 && wgrad_min_ok(P)) ? 2 : 1);
                 patch_folded = true;    // its slabs are [S][Cout][3][3][Cin_tot] already
                 rc = wgrad_patch_launch(P, st);
             } else {

@@ -419,11 +419,13 @@ int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *desc, int kind);
  * of <= 16 channels, 3x3 stride 2 pad 1, 64 outputs, even frame sides; forward
  * and weight gradient, exact f32 in every operand mode). */
 int dvsof_conv2d_kernel_generation(const dvsof_conv_desc_t *desc, int kind);
-/* 1 when the calling thread's LAST dvsof_conv2d_fwd (kind 0) / dvsof_conv2d_wgrad
- * (kind 2) ran a patch-resident decoder kernel (csrc/fwd_patch.hip,
- * csrc/wgrad_patch.hip) -- the choice depends on operand mode, twins and
- * pointer alignment, which the descriptor alone does not fix (profiling tools:
- * bench.py names its roofline groups with it) */
+/* What the calling thread's LAST dvsof_conv2d_fwd (kind 0) / _dgrad (1) / _wgrad
+ * (2) ran for a decoder stage: 0 the general kernels, 1 a patch-resident
+ * sixteen-product kernel (csrc/fwd_patch.hip, csrc/wgrad_patch.hip), 2 the
+ * nine-product minimal form (csrc/fwd_min.hip, dgrad_min.hip, wgrad_min.hip:
+ * exact f32; 9 instead of 16 matrix products per low-resolution pixel).  The
+ * choice depends on operand mode, twins and shape (profiling tools: bench.py
+ * names its roofline groups and counts executed FLOPs with it) */
 int dvsof_conv2d_last_patch(int kind);
 
 /* wt[ci][k*k-1-tap][co] = w[co][tap][ci] */
