@@ -556,6 +556,7 @@ struct PyrParams {
     float sh[DVSOF_MAX_SCALES], sw[DVSOF_MAX_SCALES];   // input step per output pixel
     int K, D, H, W;
     int tiles_x, tiles_per_frame, nblocks;
+    int big;        // 1: 32 x 128 tiles of the finest level (many frames), else 16 x 64
 };
 
 __device__ __forceinline__ int pyr_lo(float s, int o) { return (int)(s * (float)o); }
@@ -565,6 +566,13 @@ __device__ __forceinline__ int pyr_hi(float s, int o, int nin)
     return y0 + (y0 < nin - 1 ? 1 : 0);
 }
 
+// PTH x PTW: the tile of the finest level a workgroup owns.  16 x 64 at the benchmark batch
+// (1 024 workgroups); 32 x 128 when there are many frames: a workgroup's life is a chain of K
+// dependent phases behind barriers, and at batch 64 the 8 192 small workgroups were bound by
+// that chain (30-35 us for 45 MB written) -- four times the pixels per chain, and the finest
+// level leaves as 16-byte stores (4 consecutive pixels per thread; the arithmetic per pixel is
+// unchanged, so the values are still bitwise those of K dependent launches).
+template <int PTH, int PTW>
 __global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, const Params P,
                                                           const int do_count)
 {
@@ -589,12 +597,12 @@ __global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, con
         ry0[k] = ry1[k] = rx0[k] = rx1[k] = 0;
         pey[k] = pex[k] = -1;
         if (k == K - 1) {
-            ry0[k] = ty * TH;
-            ry1[k] = min(ry0[k] + TH - 1, Q.h[k] - 1);
-            rx0[k] = tx * TW;
-            rx1[k] = min(rx0[k] + TW - 1, Q.w[k] - 1);
-            pey[k] = ty * TH - 1;
-            pex[k] = tx * TW - 1;
+            ry0[k] = ty * PTH;
+            ry1[k] = min(ry0[k] + PTH - 1, Q.h[k] - 1);
+            rx0[k] = tx * PTW;
+            rx1[k] = min(rx0[k] + PTW - 1, Q.w[k] - 1);
+            pey[k] = ty * PTH - 1;
+            pex[k] = tx * PTW - 1;
         } else if (k < K - 1) {
             ry0[k] = pyr_lo(Q.sh[k + 1], ry0[k + 1]);
             ry1[k] = pyr_hi(Q.sh[k + 1], ry1[k + 1], Q.h[k]);
@@ -616,6 +624,32 @@ __global__ __launch_bounds__(NT) void loss_pyramid_kernel(const PyrParams Q, con
         float *cur = buf[k & 1];
         float *out = Q.lev[k] + (size_t)d * Q.h[k] * Q.w[k];
         const float sh = Q.sh[k], sw = Q.sw[k];
+        if (k == K - 1 && (rw & 3) == 0 && (Q.w[k] & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+            // the finest level: 4 consecutive pixels per thread, one 16-byte store (its region
+            // starts at a multiple of PTW, every pixel of it is this tile's to write)
+            const int rw4 = rw >> 2;
+            for (int i = tid; i < rh * rw4; i += NT) {
+                const int ly = i / rw4, lx = (i - ly * rw4) * 4;
+                const int y = ry0[k] + ly, x = rx0[k] + lx;
+                const float fy = sh * (float)y;
+                const int y0 = min((int)fy, hin - 1);
+                const int y1 = y0 + (y0 < hin - 1 ? 1 : 0);
+                const float wy = fy - (float)y0, hy = 1.f - wy;
+                const float *r0 = in + (size_t)(y0 - iy0) * ipitch - ix0;
+                const float *r1 = in + (size_t)(y1 - iy0) * ipitch - ix0;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float fx = sw * (float)(x + e);
+                    const int x0 = min((int)fx, win - 1);
+                    const int x1 = x0 + (x0 < win - 1 ? 1 : 0);
+                    const float wx = fx - (float)x0, hx = 1.f - wx;
+                    v[e] = hy * (hx * r0[x0] + wx * r0[x1]) + wy * (hx * r1[x0] + wx * r1[x1]);
+                }
+                *(float4 *)(out + (size_t)y * Q.w[k] + x) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            break;
+        }
         for (int i = tid; i < rh * rw; i += NT) {
             const int ly = i / rw, lx = i - ly * rw;
             const int y = ry0[k] + ly, x = rx0[k] + lx;
@@ -737,17 +771,27 @@ bool pyramid_plan(int D, int H, int W, float *const *levels, const int *hs, cons
         Q.sw[k] = ws[k] > 1 ? (float)(win - 1) / (float)(ws[k] - 1) : 0.f;
         if (k && (hs[k] < hs[k - 1] || ws[k] < ws[k - 1])) return false;
     }
-    // conservative bound of the region sizes of a TH x TW tile of the finest level
-    double rh = TH, rw = TW;
-    for (int k = K - 1; k > 0; --k) {
-        rh = rh * Q.sh[k] + 3;
-        rw = rw * Q.sw[k] + 3;
-        if (rh > hs[k - 1]) rh = hs[k - 1];
-        if (rw > ws[k - 1]) rw = ws[k - 1];
-        if (rh * rw > PYR_MAXR) return false;
-    }
-    Q.tiles_x = (ws[K - 1] + TW - 1) / TW;
-    Q.tiles_per_frame = Q.tiles_x * ((hs[K - 1] + TH - 1) / TH);
+    // conservative bound of the region sizes of a th x tw tile of the finest level
+    auto fits = [&](int th, int tw) {
+        double rh = th, rw = tw;
+        for (int k = K - 1; k > 0; --k) {
+            rh = rh * Q.sh[k] + 3;
+            rw = rw * Q.sw[k] + 3;
+            if (rh > hs[k - 1]) rh = hs[k - 1];
+            if (rw > ws[k - 1]) rw = ws[k - 1];
+            if (rh * rw > PYR_MAXR) return false;
+        }
+        return true;
+    };
+    if (!fits(TH, TW)) return false;
+    // big tiles once the small ones would be more than 8 workgroups per CU
+    // (DVSOF_PYR_BIG=0|1 forces the choice)
+    static const int force = getenv("DVSOF_PYR_BIG") ? atoi(getenv("DVSOF_PYR_BIG")) : -1;
+    const long long small = (long long)D * ((ws[K - 1] + TW - 1) / TW) * ((hs[K - 1] + TH - 1) / TH);
+    Q.big = (force == 1 || (force < 0 && small >= 2048)) && fits(2 * TH, 2 * TW) ? 1 : 0;
+    const int th = Q.big ? 2 * TH : TH, tw = Q.big ? 2 * TW : TW;
+    Q.tiles_x = (ws[K - 1] + tw - 1) / tw;
+    Q.tiles_per_frame = Q.tiles_x * ((hs[K - 1] + th - 1) / th);
     const long long nb = (long long)D * Q.tiles_per_frame;
     if (nb > 0x3fffffff) return false;
     Q.nblocks = (int)nb;
@@ -779,8 +823,12 @@ int pyramid_launch(const float *images, int D, int H, int W, float *const *level
     PyrParams Q;
     if (D > 0 && !no_fuse && pyramid_plan(D, H, W, levels, hs, ws, K, images, Q)) {
         Params dummy = {};
-        hipLaunchKernelGGL(loss_pyramid_kernel, dim3(Q.nblocks + (P ? nb_count : 0)), dim3(NT), 0, st,
-                           Q, P ? *P : dummy, P ? 1 : 0);
+        if (Q.big)
+            hipLaunchKernelGGL((loss_pyramid_kernel<2 * TH, 2 * TW>), dim3(Q.nblocks + (P ? nb_count : 0)),
+                               dim3(NT), 0, st, Q, P ? *P : dummy, P ? 1 : 0);
+        else
+            hipLaunchKernelGGL((loss_pyramid_kernel<TH, TW>), dim3(Q.nblocks + (P ? nb_count : 0)),
+                               dim3(NT), 0, st, Q, P ? *P : dummy, P ? 1 : 0);
         DVSOF_LAUNCH_CHECK();
         return DVSOF_OK;
     }

@@ -170,20 +170,25 @@ def test_baseline_size_properties():
             np.linalg.norm(a - o) / np.linalg.norm(o)
 
 
-@pytest.mark.parametrize('src,shapes', [
-    ((256, 256), [(32, 32), (64, 64), (128, 128), (256, 256)]),     # config 2
-    ((260, 346), [(33, 44), (65, 87), (130, 173), (260, 346)]),     # odd sizes
-    ((480, 640), [(60, 80), (120, 160), (240, 320), (480, 640)]),   # config 4
-    ((64, 64), [(64, 64)]),                                         # one level
-    ((96, 80), [(12, 10), (12, 10), (48, 40)]),                     # equal levels
-    ((64, 64), [(32, 32), (16, 16)]),                               # shrinking: per-level path
+@pytest.mark.parametrize('src,shapes,D', [
+    ((256, 256), [(32, 32), (64, 64), (128, 128), (256, 256)], 6),     # config 2
+    ((260, 346), [(33, 44), (65, 87), (130, 173), (260, 346)], 6),     # odd sizes
+    ((480, 640), [(60, 80), (120, 160), (240, 320), (480, 640)], 6),   # config 4
+    ((64, 64), [(64, 64)], 6),                                         # one level
+    ((96, 80), [(12, 10), (12, 10), (48, 40)], 6),                     # equal levels
+    ((64, 64), [(32, 32), (16, 16)], 6),                               # shrinking: per-level path
+    # many frames: 32 x 128 tiles of the finest level, 16-byte stores (batch 16 = 32 frames
+    # at the benchmark size; ragged right / bottom tiles at 480 x 640; a width that is no
+    # multiple of 4 takes the scalar stores)
+    ((256, 256), [(32, 32), (64, 64), (128, 128), (256, 256)], 32),
+    ((480, 640), [(60, 80), (120, 160), (240, 320), (480, 640)], 8),
+    ((260, 346), [(33, 44), (65, 87), (130, 173), (260, 346)], 24),
 ])
-def test_pyramid_one_launch_is_bitwise_the_cascade(src, shapes):
+def test_pyramid_one_launch_is_bitwise_the_cascade(src, shapes, D):
     """dvsof_loss_pyramid == K dependent dvsof_resize_bilinear_ac calls
     (utils/loss.py:207-210), bit for bit, and == torch's interpolate within
     float rounding."""
     from dvs_of_training_framework_amd.loss import Losses, interpolate
-    D = 6
     g = torch.Generator().manual_seed(5)
     img = (torch.rand(D, 1, *src, generator=g) * 255).cuda()
     ev = Losses(shapes, D // 2, 'cuda')
