@@ -186,6 +186,11 @@ __device__ __forceinline__ void final_terms(const Params &P, double (*s_tot)[3])
     }
 }
 
+#ifndef DVSOF_LOSS_NO_FENCE
+#define LOSS_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LOSS_FENCE()
+#endif
 #ifdef DVSOF_LOSS_WPE     // experiment (tools/variant.sh): registers capped for that many waves per SIMD
 #define LOSS_MAIN_ATTR __attribute__((amdgpu_waves_per_eu(DVSOF_LOSS_WPE, DVSOF_LOSS_WPE)))
 #else
@@ -194,7 +199,11 @@ __device__ __forceinline__ void final_terms(const Params &P, double (*s_tot)[3])
 template <bool FWD, bool BWD>
 __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Params P)
 {
-    __shared__ float sF[2][LH][LW];
+    // flow tile + 1-pixel halo, (u, v) interleaved: a pair is one ds_read_b64 into an aligned
+    // register pair (the packed-f32 operand as it stands; two planes cost ~180 v_mov per wave
+    // to assemble pairs).  Padded to FILL x NT entries: the fill writes unconditionally.
+    constexpr int FILL = (LH * LW + NT - 1) / NT;
+    __shared__ f32x2 sF[FILL * NT];
     __shared__ float red[NW][NPART];
     __shared__ int s_cnt[NW];
 
@@ -216,28 +225,27 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
     // load -> wait -> ds_write round trips, and a workgroup's life is a chain of
     // such round trips: at batch 8 every workgroup is resident at once and the
     // kernel takes exactly as long as one workgroup does)
+    // Out-of-frame entries read as zero through the buffer range check (an offset past the
+    // sample's two planes), like the frame taps below: no exec-masked loads, no branches.
     {
-        constexpr int FILL = (LH * LW + NT - 1) / NT;
+        const __amdgpu_buffer_rsrc_t rf =
+            __builtin_amdgcn_make_buffer_rsrc((void *)U, 0, (int)(2 * hw * 4), 0x00020000);
+        constexpr unsigned OOB = 0xffffffffu;
         float fu[FILL], fv[FILL];
 #pragma unroll
         for (int it = 0; it < FILL; ++it) {
             const int i = tid + it * NT;
             const int ly = i / LW, lx = i - ly * LW;
             const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
-            const bool in = (i < LH * LW) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
-            const size_t o = in ? (size_t)gy * w + gx : 0;
-            fu[it] = in ? U[o] : 0.f;
-            fv[it] = in ? U[hw + o] : 0.f;
+            const bool in = (i < LH * LW) & ((unsigned)gy < (unsigned)h) & ((unsigned)gx < (unsigned)w);
+            const unsigned o = (unsigned)((gy * w + gx) * 4);
+            fu[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, in ? o : OOB, 0, 0));
+            fv[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, in ? o + (unsigned)(hw * 4) : OOB, 0, 0));
         }
 #pragma unroll
-        for (int it = 0; it < FILL; ++it) {
-            const int i = tid + it * NT;
-            if (i < LH * LW) {
-                (&sF[0][0][0])[i] = fu[it];
-                (&sF[1][0][0])[i] = fv[it];
-            }
-        }
+        for (int it = 0; it < FILL; ++it) sF[tid + it * NT] = f32x2{fu[it], fv[it]};
     }
+    auto F2 = [&](int ly, int lx) -> f32x2 { return sF[ly * LW + lx]; };
     const float *I0 = S.frames + (size_t)P.start[n] * hw;
     const float *I1 = S.frames + (size_t)P.stop[n] * hw;
     float seed[3] = {0.f, 0.f, 0.f};
@@ -284,7 +292,8 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
         for (int j = 0; j < NP; ++j) {
             const int ly = ly0 + j, y = ty0 + ly;
             valid[j] = (y < h) & (x < w);
-            const float u = sF[0][ly + 1][lane + 1], v = sF[1][ly + 1][lane + 1];
+            const f32x2 uv = F2(ly + 1, lane + 1);
+            const float u = uv.x, v = uv.y;
             float gx, gy;
             warp_grid(S, x, y, u, v, gx, gy);
             oobv[j] = out_of_border(gx, gy);
@@ -319,7 +328,8 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
         const int db = kind == 1 ? -1 : (kind == 2 ? 1 : 0);
         const int ya = ty0 + ly0 + r, yb = ya + db;
         const bool ok = (tx0 >= 1) & (ya >= 0) & (ya < h) & (yb >= 0) & (yb < h);
-        const float fa = sF[c][ly0 + r + 1][1], fb = sF[c][ly0 + r + 1 + db][0];
+        const f32x2 fa2 = F2(ly0 + r + 1, 1), fb2 = F2(ly0 + r + 1 + db, 0);
+        const float fa = c ? fa2.y : fa2.x, fb = c ? fb2.y : fb2.x;
         edge = ok ? charbonnier(fa - fb).der : 0.f;
     }
     const int edge_bits = __builtin_bit_cast(int, edge);
@@ -330,6 +340,12 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
     float gu[NP], gv[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) gu[j] = gv[j] = 0.f;
+    // Scheduling fences between the phases (gathers | photometric | smoothness rows | tail).
+    // As ONE scheduling region the compiler interleaves all of it for instruction-level
+    // parallelism: 152 registers, 3 waves per SIMD.  The probe build, whose runtime probe
+    // tests happen to cut the region in the same places, needs 80 (6 waves per SIMD) and was
+    // 10 % faster at batch 64: this kernel wants occupancy, not a longer in-order window.
+    LOSS_FENCE();
     // photometric + out-of-border, utils/loss.py:58-74, 96-119
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -345,8 +361,8 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
             gv[j] = gp * ((sw - nw) * cx + (se - ne) * ax);
         }
         if (oobv[j]) {
-            const Charb bu = charbonnier(sF[0][ly0 + j + 1][lane + 1]),
-                        bv = charbonnier(sF[1][ly0 + j + 1][lane + 1]);
+            const f32x2 buv = F2(ly0 + j + 1, lane + 1);
+            const Charb bu = charbonnier(buv.x), bv = charbonnier(buv.y);
             if (FWD) {
                 acc[5] += bu.val + bv.val;
                 acc[6] += 1.f;
@@ -357,6 +373,7 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
             }
         }
     }
+    LOSS_FENCE();
     // smoothness, utils/loss.py:76-90.  Anchor (r, x), r = -1..3 relative to the
     // strip: d0 = rho'(F[r][x+1] - F[r][x]), d1 = rho'(F[r+1][x] - F[r][x]),
     // d2 = rho'(F[r+1][x+1] - F[r][x]), d3 = rho'(F[r][x+1] - F[r+1][x]).
@@ -365,7 +382,13 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
     // Branch-free: the LDS halo is zero-filled outside the frame, so every pair
     // can be evaluated and then multiplied by its 0/1 validity.  The two flow
     // channels of a pair go through the arithmetic together (packed f32).
-    if (!(DVSOF_DBG(P) & 1)) {
+    // (`h > 0` is always true: a wave-uniform branch the compiler cannot fold makes this
+    // section a scheduling region of its own.  Without it the smoothness rows are interleaved
+    // with the gathers' waits and the photometric part for instruction-level parallelism:
+    // 154 registers, 3 waves per SIMD; with it 77 and 6 -- the sweep is bound by latency and
+    // issue slots across waves, not by one wave's in-order window.  sched_barrier fences alone
+    // did not move the allocation.)
+    if (h > 0 && !(DVSOF_DBG(P) & 1)) {
         const float mx = x < w ? 1.f : 0.f, mxr = x + 1 < w ? 1.f : 0.f;
         float mrow[6];                     // rows -1..4 of the strip inside the frame
 #pragma unroll
@@ -377,15 +400,15 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
         // r and r - 1 in hand, pixel row r is complete -- only two rows of
         // derivatives live in registers (all five: 70 VGPRs more, occupancy 3).
         f32x2 s1 = {0.f, 0.f}, s2 = s1, s3 = s1, s4 = s1;
-        f32x2 p0 = {sF[0][ly0][lane + 1], sF[1][ly0][lane + 1]};     // row -1: columns x, x + 1
-        f32x2 p1 = {sF[0][ly0][lane + 2], sF[1][ly0][lane + 2]};
+        f32x2 p0 = F2(ly0, lane + 1);     // row -1: columns x, x + 1
+        f32x2 p1 = F2(ly0, lane + 2);
         f32x2 d1p = s1, d2p = s1, d3p = s1;                           // anchor row r - 1
         const float k0 = S.k_smooth[0] * seed[0], k1 = S.k_smooth[1] * seed[0],
                     k2 = S.k_smooth[2] * seed[0];
 #pragma unroll
         for (int r = 0; r < 5; ++r) {          // anchor strip row r - 1
-            const f32x2 n0 = {sF[0][ly0 + r + 1][lane + 1], sF[1][ly0 + r + 1][lane + 1]};
-            const f32x2 n1 = {sF[0][ly0 + r + 1][lane + 2], sF[1][ly0 + r + 1][lane + 2]};
+            const f32x2 n0 = F2(ly0 + r + 1, lane + 1);
+            const f32x2 n1 = F2(ly0 + r + 1, lane + 2);
             const bool own = r >= 1;           // anchor row of this strip: sums count
             const float m0 = mrow[r] * mxr, mv = mrow[r] * mrow[r + 1];
             const float m1 = mv * mx, m2 = mv * mxr;
@@ -406,18 +429,16 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
             const f32x2 d1c = q1.der * m1, d2c = q2.der * m2, d3c = q3.der * m2;
             if (BWD && own) {
                 const int j = r - 1;
-                // from the column to the left: lane - 1, or the edge row for lane 0
-                f32x2 in0 = {__shfl_up(d0c.x, 1, kWave), __shfl_up(d0c.y, 1, kWave)};
-                f32x2 in2 = {__shfl_up(d2p.x, 1, kWave), __shfl_up(d2p.y, 1, kWave)};
-                f32x2 in3 = {__shfl_up(d3c.x, 1, kWave), __shfl_up(d3c.y, 1, kWave)};
-                // (selects, not a branch: a divergent `if (lane == 0)` here cost 80 VGPRs)
-                const bool first = lane == 0;
-                in0.x = first ? edge_at(j) : in0.x;
-                in0.y = first ? edge_at(12 + j) : in0.y;
-                in2.x = first ? edge_at(4 + j) : in2.x;
-                in2.y = first ? edge_at(16 + j) : in2.y;
-                in3.x = first ? edge_at(8 + j) : in3.x;
-                in3.y = first ? edge_at(20 + j) : in3.y;
+                // from the column to the left: lane - 1 by a DPP wave shift (wave_shr:1; __shfl_up
+                // is a ds_bpermute through the LDS crossbar); lane 0 keeps the shift's `old`
+                // operand = the edge column's value (no select, no branch)
+                auto from_left = [&](float v, int src) -> float {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        __builtin_bit_cast(int, edge_at(src)), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+                };
+                const f32x2 in0 = {from_left(d0c.x, j), from_left(d0c.y, 12 + j)};
+                const f32x2 in2 = {from_left(d2p.x, 4 + j), from_left(d2p.y, 16 + j)};
+                const f32x2 in3 = {from_left(d3c.x, 8 + j), from_left(d3c.y, 20 + j)};
                 const f32x2 g = (in0 - d0c) * k0 + (d1p - d1c) * k1 + ((in2 - d2c) + (in3 - d3p)) * k2;
                 gu[j] += g.x;
                 gv[j] += g.y;
@@ -427,6 +448,7 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
             d3p = d3c;
             p0 = n0;
             p1 = n1;
+            LOSS_FENCE();
         }
         if (FWD) {
             acc[1] = s1.x + s1.y;
@@ -435,18 +457,23 @@ __global__ __launch_bounds__(NT) LOSS_MAIN_ATTR void loss_main_kernel(const Para
             acc[4] = s4.x + s4.y;
         }
     }
+    LOSS_FENCE();
     // ---- tail.  Waves 1..3 store their gradients and RETIRE; wave 0 alone
     // adds the workgroup's sums to its group's accumulators and, on small
     // grids, bumps the arrival counter, stores its own gradients while that
     // atomic is in flight, and combines everything if it was the last.
     auto store_grads = [&]() {
         if (!BWD || (DVSOF_DBG(P) & 8)) return;
+        // pixels outside the frame get an offset past the sample's two planes: the buffer
+        // range check drops the store (no exec-masked branches around 8 stores)
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(S.grad + (size_t)n * 2 * hw), 0, (int)(2 * hw * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            if (!valid[j]) continue;
-            float *G = S.grad + (size_t)n * 2 * hw + (size_t)(ty0 + ly0 + j) * w + x;
-            G[0] = gu[j];
-            G[hw] = gv[j];
+            const unsigned o = valid[j] ? (unsigned)(((ty0 + ly0 + j) * w + x) * 4) : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gu[j]), rg, o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gv[j]), rg,
+                                                  valid[j] ? o + (unsigned)(hw * 4) : 0xffffffffu, 0, 0);
         }
     };
     if (!FWD || (DVSOF_DBG(P) & 16)) {
