@@ -222,7 +222,8 @@ class Harness:
         fo = getattr(a, 'fused_optimizer', 'auto')
         if fo == 'auto':    # measured: +1.5 % in f32 on one GPU; behind the exchange marks of a
             # (1-rank) group the per-bucket waits cost more than the overlap gives (-6 %)
-            alone = int(os.environ.get('WORLD_SIZE', '1')) == 1 and os.environ.get('DVSOF_FORCE_DIST') != '1'
+            alone = int(os.environ.get('WORLD_SIZE', '1')) == 1 and os.environ.get('DVSOF_FORCE_DIST') != '1' \
+                and not os.environ.get('DVSOF_LOOPBACK')
             fo = 'buckets' if getattr(a, 'dtype', 'f32') == 'f32' and alone else 'none'
         if fo != 'none':
             self.opt.fuse_into_backward(self.model.predictor,
@@ -750,7 +751,11 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     h = Harness(a, rank, device)
-    if world > 1 or os.environ.get('DVSOF_FORCE_DIST') == '1':
+    if world > 1 or os.environ.get('DVSOF_FORCE_DIST') == '1' or os.environ.get('DVSOF_LOOPBACK'):
+        # (DVSOF_LOOPBACK="world:delay_us": the loopback communicator -- a late, non-identity
+        # exchange on one GPU: what the plumbing of the exchange costs when collectives take time)
+        if os.environ.get('DVSOF_LOOPBACK'):
+            parallel.claim_streams(device)
         parallel.broadcast_parameters(h.model)
         # ONE communicator -- the C ABI's own (dvsof_comm_create, made here) -- carries the
         # exchange of replayed and eager steps alike; DVSOF_DIRECT_RCCL=0 with --eager:
@@ -809,9 +814,13 @@ def main():
             # the C ABI's communicator; the process group's size on the torch.distributed path)
             info = h.reducer.comm_info()
             out['config']['rccl_ranks'] = info['ranks'] if info else torch.distributed.get_world_size()
+            if info and info['loopback']:
+                out['config']['rccl_ranks'] = 0
+                out['config']['loopback_world'] = info['ranks']
             out['config']['exchange'] = (
                 f"{info['calls']} bucket all-reduces ({info['elements'] * 4 / 1e6:.1f} MB) on the C ABI's "
-                'RCCL communicator (dvsof_allreduce_bucket)' if info else
+                + ('LOOPBACK communicator (no peers: bucket / world, late)' if info['loopback'] else 'RCCL communicator')
+                + ' (dvsof_allreduce_bucket)' if info else
                 f'{h.reducer.bytes_reduced / 1e6:.1f} MB through torch.distributed (process group nccl)')
     if rank == 0:
         out['config']['launch'] = getattr(h, 'launch_fallback', None) or \

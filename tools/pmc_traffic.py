@@ -16,9 +16,9 @@ import pandas as pd
 def load(d, counter):
     c = pd.read_csv(f'{d}/pmc_counter_collection.csv')
     c = c[(c.Counter_Name == counter) &
-          c.Kernel_Name.str.contains(r'gconv\d?_kernel|wgrad\d?_kernel|wino_\w+_kernel|\w+_patch_\w+_kernel')].copy()
+          c.Kernel_Name.str.contains(r'gconv\d?_kernel|wgrad\d?_kernel|wino_\w+_kernel|\w+_patch_\w+_kernel|\w+_min_f32_kernel')].copy()
     c['k'] = c.Kernel_Name.map(lambda n: re.sub(
-        r'\s', '', re.search(r'((?:gconv\d?|wgrad\d?|wino_\w+|\w+_patch_\w+)_kernel<[^>]*>)', n).group(1)))
+        r'\s', '', re.search(r'((?:gconv\d?|wgrad\d?|wino_\w+|\w+_patch_\w+|\w+_min_f32)_kernel(?:<[^>]*>)?)', n).group(1)))
     c['dur'] = (c.End_Timestamp - c.Start_Timestamp) / 1e3
     return c.groupby('k').agg(n=('Counter_Value', 'size'), val=('Counter_Value', 'mean'),
                               dur=('dur', 'mean'))
