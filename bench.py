@@ -460,6 +460,24 @@ def measure_roofline(h, step_ms, steps=3, light=False):
         else PEAK_F32_MATRIX_TFLOPS
     T = 1e12
 
+    EB = 2 if getattr(h.a, 'dtype', 'f32') == 'bf16s' else 4   # bytes per operand element in LDS
+    LDS_DMA_TBS = 6.3       # L2 -> LDS stream, chip-wide (MI355X_MICROARCH.md: ldsdma-fill 6.4)
+
+    def lds_stream(name, v):
+        """Bytes the general implicit-GEMM kernels move L2 -> LDS per launch: a BM x BN tile
+        streams (BM + BN) K elements for 2 BM BN K FLOPs, so bytes = executed FLOPs / 2 x
+        (1 / BM + 1 / BN) x element size -- the bound that applies to the bf16 modes (the
+        matrix pipes are idle 85-95 % of the time there).  None for the patch-resident /
+        nine-product / first-layer / Winograd-transform groups (they stream a patch once)."""
+        import re
+        m = re.search(r'(?:gconv2|wgrad2)_kernel<[^>]*> (\d+)x(\d+)$', name)
+        if not m:
+            return None
+        bm, bn = int(m.group(1)), int(m.group(2))
+        nbytes = v[3] / 2.0 * (1.0 / bm + 1.0 / bn) * EB
+        return {'bytes_per_launch': round(nbytes / v[0]), 'TBps': round(nbytes / v[2] / 1e12, 2),
+                'frac_of_lds_dma_peak': round(nbytes / v[2] / 1e12 / LDS_DMA_TBS, 3)}
+
     def rates(v):       # (launches, algorithmic flops, seconds, executed flops)
         return {'launches': v[0] // steps, 'avg_launch_us': round(v[2] / v[0] * 1e6, 2),
                 'ms_per_step': round(v[2] / steps * 1e3, 3),
@@ -533,7 +551,15 @@ def measure_roofline(h, step_ms, steps=3, light=False):
                  'frac': round(tot[3] / steps / step_ms / 1e9 / peak, 4),
                  'algorithmic_tflops': round(tot[1] / steps / step_ms / 1e9, 2)},
         'hbm': hbm,
-        'per_kernel': {k: rates(v) for k, v in agg.items()}}
+        'per_kernel': {k: dict(rates(v), lds_stream=lds_stream(k, v)) for k, v in agg.items()}}
+    # the bound of the dominant group when it is not the matrix pipe: its L2 -> LDS stream
+    roof['lds_stream'] = lds_stream(dom, agg[dom])
+    # ... and of the largest general-kernel group (the dominant one may be a patch kernel)
+    gen = [k for k in agg if lds_stream(k, agg[k])]
+    if gen:
+        g = max(gen, key=lambda k: agg[k][2])
+        roof['lds_stream_largest_general'] = dict(lds_stream(g, agg[g]), kernel=g,
+                                                  ms_per_step=round(agg[g][2] / steps * 1e3, 3))
     return roof
 
 
@@ -867,7 +893,11 @@ def main():
                 others[dt]['roofline'] = {
                     'bound': 'mfma', 'peak': r2['peak'], 'unit': 'TFLOP/s', 'kernel': r2['kernel'],
                     'achieved': r2['achieved'], 'frac': r2['frac'], 'avg_launch_us': r2['avg_launch_us'],
-                    'step': r2['step'], 'conv_stack_single_stream': r2['conv_stack_single_stream']}
+                    'step': r2['step'], 'conv_stack_single_stream': r2['conv_stack_single_stream'],
+                    # the bound that applies to these modes: bytes through LDS-DMA against the
+                    # ~6.3 TB/s the L2 -> LDS stream reaches chip-wide
+                    'lds_stream': r2.get('lds_stream'),
+                    'lds_stream_largest_general': r2.get('lds_stream_largest_general')}
             del h2
         others['note'] = ('matrix-core operand modes with f32 accumulation: bf16x3 = hi+lo split '
                           'operands, three products (flows within 4e-6, gradients 9e-5 of the exact '
@@ -875,7 +905,8 @@ def main():
                           'activations / gradients / weight forms streamed through LDS; roofline: '
                           'executed matrix FLOPs against the DENSE bf16 peak (2516.6 TF/s) -- these '
                           'modes are bound by bytes through LDS / HBM, not by the matrix pipes '
-                          '(DESIGN section 4)')
+                          '(DESIGN section 4): lds_stream = L2 -> LDS bytes of the general implicit-GEMM '
+                          'kernels / their time / 6.3 TB/s')
         out['other_modes'] = others
     if rank == 0 and world == 1 and not a.no_train_loop:
         if 'h' in dir():

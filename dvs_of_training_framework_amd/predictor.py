@@ -459,7 +459,7 @@ class _PredictorFn(torch.autograd.Function):
         # wait for it -- this way both streams drain the tail together.
         gz, gz16 = gs, gs16
         deferred = []
-        n_side = int(os.environ.get('DVSOF_ENC_SIDE_FROM', '2'))
+        n_side = int(os.environ.get('DVSOF_ENC_SIDE_FROM', '3'))
         for i in (3, 2, 1, 0):
             lay = enc_l[i]
             item = (lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i),
