@@ -357,17 +357,25 @@ int dvsof_conv2d_winograd_tile(const dvsof_conv_desc_t *desc, int kind);
 
 /*
  * Prepared weights.  An upsampled 3x3/pad-1 layer is evaluated as four 2x2
- * sub-pixel phase convolutions on the low-resolution input (2.25x fewer
- * multiply-adds, same result up to fp32 summation order); its forward
- * weights are Wf[4][Cout][2][2][Ctot] and its data-gradient weights the 4x4
- * stride-2 kernel Wd[Ctot][4][4][Cout].  Every other layer uses the raw
- * weights forward and their tap-flipped transpose backward.
+ * sub-pixel phase convolutions on the low-resolution input (16 instead of 36
+ * tap-products per low-resolution pixel, same result up to fp32 summation
+ * order): forward weights Wf[4][Cout][2][2][Ctot], data-gradient weights the
+ * 4x4 stride-2 kernel Wd[Ctot][4][4][Cout] -- or, in exact f32 (mfma == 0)
+ * with two NHWC members of 32 | C, 32 | Cout, 16 | W, 4 | H, by the minimal
+ * bilinear algorithm of csrc/fwd_min.hip with NINE products: forward weights
+ * Wt[9][Cout][Ctot] = G w G^T, and (64 | C, 8 | H) data-gradient weights
+ * W'[9][Ctot][Cout] = G' w G'^T.  Which form a buffer holds is a function of
+ * the descriptor alone (the same test picks the kernel at launch); the buffer
+ * sizes are those of the sub-pixel forms either way.  Every other layer uses
+ * the raw weights forward and their tap-flipped transpose backward.
  * dvsof_conv2d_prepare fills w_fwd (may be NULL when
  * dvsof_conv2d_fwd_weight_elems == Cout*k*k*Ctot: forward then takes the raw
  * weights) and w_dgrad (may be NULL) from the raw [Cout][k][k][Ctot] weights.
- * For a sub-pixel layer, weight == NULL means "w_fwd already holds the phase
- * kernels of an earlier call": only w_dgrad is derived from them (lets a
- * caller make the data-gradient form later, e.g. on another stream).
+ * For a sub-pixel layer w_fwd == NULL with w_dgrad makes the data-gradient
+ * form alone, from the raw weights (lets a caller make it later, e.g. on
+ * another stream).  (Sixteen-product form only: weight == NULL means "w_fwd
+ * already holds the phase kernels of an earlier call" and w_dgrad is derived
+ * from them -- DVSOF_EINVAL for a layer whose forward form is Wt.)
  */
 size_t dvsof_conv2d_fwd_weight_elems(const dvsof_conv_desc_t *desc);
 size_t dvsof_conv2d_dgrad_weight_elems(const dvsof_conv_desc_t *desc);
