@@ -84,6 +84,11 @@ CASES = [
     dict(B=3, H=24, W=48, src=[(64, 'nhwc'), (32, 'nhwc')], Cout=96, up=True, act='none'),
     dict(B=8, H=16, W=16, src=[(256, 'nhwc'), (256, 'nhwc')], Cout=128, up=True),
     dict(B=16, H=16, W=32, src=[(32, 'nhwc'), (32, 'nhwc')], Cout=32, up=True),
+    # the coarsest and the finest decoder stage EXACTLY as benchmarked (batch 8, 256 x 256
+    # input): 512 + 512 -> 256 at 16 x 16 (4-row blocks, K split over the waves, 32 chunks)
+    # and 64 + 64 -> 32 at 128 x 128 (8-row blocks, 1 024 workgroups)
+    dict(B=8, H=16, W=16, src=[(512, 'nhwc'), (512, 'nhwc')], Cout=256, up=True),
+    dict(B=8, H=128, W=128, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
 ]
 
 
@@ -211,6 +216,11 @@ def test_conv_fwd_dgrad_wgrad(ci, mfma, close=close):
     dict(B=3, H=24, W=48, src=[(64, 'nhwc'), (32, 'nhwc')], Cout=96, up=True, act='none'),
     dict(B=8, H=16, W=16, src=[(256, 'nhwc'), (256, 'nhwc')], Cout=128, up=True),
     dict(B=16, H=16, W=32, src=[(32, 'nhwc'), (32, 'nhwc')], Cout=32, up=True),
+    # the coarsest and the finest decoder stage EXACTLY as benchmarked (batch 8, 256 x 256
+    # input): 512 + 512 -> 256 at 16 x 16 (4-row blocks, K split over the waves, 32 chunks)
+    # and 64 + 64 -> 32 at 128 x 128 (8-row blocks, 1 024 workgroups)
+    dict(B=8, H=16, W=16, src=[(512, 'nhwc'), (512, 'nhwc')], Cout=256, up=True),
+    dict(B=8, H=128, W=128, src=[(64, 'nhwc'), (64, 'nhwc')], Cout=32, up=True),
 ])
 def test_wgrad_on_bf16_twins_equals_the_operand_mode(case):
     """mfma mode 3: the vector members' weight gradient streams the bf16 TWINS
