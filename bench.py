@@ -798,6 +798,14 @@ def main():
     for _ in range(4):
         h.step()
     h.settle()
+    if world > 1:
+        # every rank must have issued the same number of steps (= the same collectives) before
+        # the timed region: settling is deterministic, but a rank whose recording failed leaves
+        # it early -- level the step counters at the maximum
+        t = torch.tensor([h.i], device=device, dtype=torch.int64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        while h.i < int(t):
+            h.step()
     for _ in range(a.warmup):
         h.step()
     barrier()
