@@ -459,8 +459,11 @@ class _PredictorFn(torch.autograd.Function):
         # wait for it -- this way both streams drain the tail together.
         gz, gz16 = gs, gs16
         deferred = []
-        # (measured, batch 8: exact f32 with the nine-product decoder kernels 3, the bf16 modes 2)
-        n_side = int(os.environ.get('DVSOF_ENC_SIDE_FROM', '3' if ctx.module.mfma == 0 else '2'))
+        # (measured, batch 8: exact f32 on one GPU with the nine-product decoder kernels 3; the
+        # bf16 modes and every data-parallel rank 2)
+        red_ = getattr(ctx.module, 'reducer', None)
+        alone_ = red_ is None or not red_.active()   # (under the exchange marks 2 again: 2.72 vs 2.84 ms)
+        n_side = int(os.environ.get('DVSOF_ENC_SIDE_FROM', '3' if ctx.module.mfma == 0 and alone_ else '2'))
         for i in (3, 2, 1, 0):
             lay = enc_l[i]
             item = (lay['desc'], gz, grads[2 * i], grads[2 * i + 1], ('enc', i),
