@@ -54,7 +54,11 @@ def claim_streams(device):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     side = Predictor._wgrad_stream(None, dev)
     if key not in _EXCHANGE_STREAMS:
-        _EXCHANGE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        # highest priority the runtime offers (-1 here): a collective's kernels should not queue
+        # for CU slots behind the matrix kernels of the two compute lanes, which fill every CU
+        # (one workgroup with ~all of its LDS each) -- small kernels of the other lane were seen
+        # waiting 20-70 us for a slot (profiles/round4/timeline.txt)
+        _EXCHANGE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1)
         for s in (torch.cuda.current_stream(dev), side, _EXCHANGE_STREAMS[key]):
             if s is not None:
                 with torch.cuda.stream(s):
