@@ -32,7 +32,8 @@ class ConvDesc(ctypes.Structure):
 class GradDst(ctypes.Structure):
     """dvsof_grad_dst_t"""
     _fields_ = [('p', _vp), ('addend', _vp), ('addend2', _vp),
-                ('actsrc', _vp), ('p16', _vp)]
+                ('actsrc', _vp), ('p16', _vp), ('head_w', _vp),
+                ('head_gflow', _vp)]
 
 
 _P = ctypes.POINTER
@@ -41,6 +42,7 @@ _lib.register('dvsof_conv2d_fwd', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp, _vp,
 _lib.register('dvsof_conv2d_dgrad', _i, [_P(ConvDesc), _vp, _vp, _P(GradDst),
                                          _i, _vp])
 _lib.register('dvsof_conv2d_wgrad_workspace_bytes', _sz, [_P(ConvDesc)])
+_lib.register('dvsof_conv2d_dgrad_fuses_head', _i, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_wgrad', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp,
                                          _sz, _vp])
 _lib.register('dvsof_weight_flip_transpose', _i, [_vp, _vp, _i, _i, _i, _vp])
@@ -268,6 +270,8 @@ def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE, weight16=None,
         arr[i].addend2 = _lib.ptr(d.get('addend2'))
         arr[i].actsrc = _lib.ptr(d.get('actsrc'))
         arr[i].p16 = _lib.ptr(d.get('p16'))
+        arr[i].head_w = _lib.ptr(d.get('head_w'))
+        arr[i].head_gflow = _lib.ptr(d.get('head_gflow'))
     desc.w16 = _lib.ptr(weight16)
     desc.gout16 = _lib.ptr(gout16)
     ws = _scratch(desc, gout.device)     # noqa: F841
@@ -353,13 +357,21 @@ def heads_fwd(items, B, out=None):
     return flows
 
 
+def dgrad_fuses_head(desc):
+    """Does this layer's data gradient accept dsts[i]['head_w'] / ['head_gflow']
+    (the flow head on a source folded into the epilogue)?"""
+    return bool(_lib.lib().dvsof_conv2d_dgrad_fuses_head(ctypes.byref(desc)))
+
+
 def head_bwd(x, w, gflow, gx_in, actsrc, act, gx, dw, dbias, B, H, W, C,
              gx16=None):
+    """gx=None: the head's weight / bias gradient only (its data part went
+    into the epilogue of the data gradient that produced the tensor)."""
     nbytes = _lib.lib().dvsof_flow_head_bwd_workspace_bytes(B, H, W, C)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().dvsof_flow_head_bwd(
         x.data_ptr(), w.data_ptr(), gflow.data_ptr(), _lib.ptr(gx_in),
-        _lib.ptr(actsrc), act, gx.data_ptr(), dw.data_ptr(),
+        _lib.ptr(actsrc), act, _lib.ptr(gx), dw.data_ptr(),
         _lib.ptr(dbias), B, H, W, C, ws.data_ptr(), nbytes, _lib.ptr(gx16),
         _lib.stream()), 'dvsof_flow_head_bwd')
 

@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
                 s0 += g0;
                 s1 += g1;
             }
+            if (!gx) continue;      // weight / bias gradient only (wave-uniform)
             f32x4 g = g0 * w0 + g1 * w1;
             if (gx_in) g += *(const f32x4u *)(gx_in + o);
             if (actsrc) {
@@ -819,6 +820,12 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     return gconv_launch(P, 0, as_stream(stream));
 }
 
+int dvsof_conv2d_dgrad_fuses_head(const dvsof_conv_desc_t *d)
+{
+    int Ctot, Ho, Wo;
+    return d && desc_ok(d, Ctot, Ho, Wo) && is_min9_dgrad(d) ? 1 : 0;
+}
+
 int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const float *gout,
                        const dvsof_grad_dst_t *dst, int bwd_act, void *stream)
 {
@@ -832,7 +839,10 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         if (!dst[i].p) return DVSOF_EINVAL;
         const GSrc g = make_src(nullptr, d->src[i].C, d->src[i].layout, d->H, d->W);
         P.dst[i] = {dst[i].p, dst[i].addend, dst[i].addend2, dst[i].actsrc, g.sb, g.sy, g.sx, g.sc, g.C, 0, 0,
-                    (d->mfma == 3 && d->src[i].layout == DVSOF_NHWC) ? (unsigned short *)dst[i].p16 : nullptr};
+                    (d->mfma == 3 && d->src[i].layout == DVSOF_NHWC) ? (unsigned short *)dst[i].p16 : nullptr,
+                    dst[i].head_w, dst[i].head_gflow};
+        if ((dst[i].head_w != nullptr) != (dst[i].head_gflow != nullptr)) return DVSOF_EINVAL;
+        if (dst[i].head_w && !is_min9_dgrad(d)) return DVSOF_EINVAL;   // only dgrad_min.hip folds a head
     }
     P.W = weight_t;
     P.W16 = d->mfma == 3 ? (const unsigned short *)d->w16 : nullptr;
@@ -1320,7 +1330,9 @@ int dvsof_flow_head_bwd(const float *x, const float *w, const float *gflow, cons
                         const float *actsrc, int act, float *gx, float *dw, float *dbias, int B,
                         int H, int W, int C, void *ws, size_t ws_bytes, void *gx16, void *stream)
 {
-    if (!x || !w || !gflow || !gx || !dw || !ws || B < 1 || H < 1 || W < 1 || !head_c_ok(C))
+    // gx == NULL: the head's own weight / bias gradient only (its data part was folded into the
+    // data gradient that produced gx_in's tensor: dvsof_grad_dst_t.head_w)
+    if (!x || !w || !gflow || !dw || !ws || B < 1 || H < 1 || W < 1 || !head_c_ok(C))
         return DVSOF_EINVAL;
     if (ws_bytes < dvsof_flow_head_bwd_workspace_bytes(B, H, W, C)) return DVSOF_ENOSPACE;
     hipStream_t st = as_stream(stream);

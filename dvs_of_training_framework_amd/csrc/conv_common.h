@@ -40,6 +40,8 @@ struct GDst {
     int C;
     int ph_y, ph_x;       // element offsets of output phase (py, px)
     unsigned short *p16;  // optional bf16 twin of p, written with the same offsets
+    const float *head_w;  // optional (dgrad_min.hip only): [2][C] weights of a flow head on this member
+    const float *head_g;  // ... and the flow's gradient, planar [B][2][H][W]
 };
 
 struct GConvParams {

@@ -243,6 +243,13 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
     const GDst &D = P.dst[sel];
     const int cm = cit - (sel ? c_first : 0);
     const int ecq = lane & 7;
+    // a flow head folded into this member's gradient (dvsof_grad_dst_t.head_w): the head's
+    // two weight rows for this lane's 4 channels
+    f32x4 hw0 = {0.f, 0.f, 0.f, 0.f}, hw1 = hw0;
+    if (D.head_w) {
+        hw0 = *(const f32x4 *)(D.head_w + cm + 4 * ecq);
+        hw1 = *(const f32x4 *)(D.head_w + D.C + cm + 4 * ecq);
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int px = 8 * it + (lane >> 3);
@@ -253,6 +260,11 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
         const long long o = (long long)b * D.sb + (long long)yy * D.sy + (long long)xx * D.sx + cm + 4 * ecq;
         if (D.addend) v += *(const f32x4 *)(D.addend + o);
         if (D.addend2) v += *(const f32x4 *)(D.addend2 + o);
+        if (D.head_w) {     // + W_h^T g_flow at this pixel (dvsof_flow_head_bwd's data part)
+            const long long hwp = (long long)H * W, r = (long long)yy * W + xx;
+            const float g0 = D.head_g[((long long)b * 2) * hwp + r], g1 = D.head_g[((long long)b * 2 + 1) * hwp + r];
+            v += g0 * hw0 + g1 * hw1;
+        }
         if (D.actsrc) {
             const f32x4 a = *(const f32x4 *)(D.actsrc + o);
 #pragma unroll
@@ -291,7 +303,8 @@ int dgrad_min_launch(const GConvParams &P, hipStream_t st)
         const GDst &D = P.dst[i];
         if (!D.p || D.sc != 1 || ((D.sb | D.sy | D.sx) & 3)) return DVSOF_EINVAL;
         if ((reinterpret_cast<uintptr_t>(D.p) | reinterpret_cast<uintptr_t>(D.addend) |
-             reinterpret_cast<uintptr_t>(D.addend2) | reinterpret_cast<uintptr_t>(D.actsrc)) & 15)
+             reinterpret_cast<uintptr_t>(D.addend2) | reinterpret_cast<uintptr_t>(D.actsrc) |
+             reinterpret_cast<uintptr_t>(D.head_w)) & 15)
             return DVSOF_EINVAL;
     }
     static bool attr_set = false;

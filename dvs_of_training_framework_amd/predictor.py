@@ -354,8 +354,10 @@ class _PredictorFn(torch.autograd.Function):
         # weight gradient, ahead of it on the same stream.
         pending = []
 
-        def wgrad(desc, gz, gw, gb, unit, gz16=None, fold=None):
+        def wgrad(desc, gz, gw, gb, unit, gz16=None, fold=None, first=None):
             def body():
+                if first is not None:
+                    first()
                 for job in pending:
                     job()
                 del pending[:]
@@ -393,23 +395,37 @@ class _PredictorFn(torch.autograd.Function):
         g_f = gflows[3]     # total gradient of the flow of this stage
         g_skip = [None] * 4  # gradient into e[k] from the decoder
         g_r = g_r16 = None
+        head_in_dgrad = False
+        fuse_heads = os.environ.get('DVSOF_NO_HEAD_FUSE', '0') == '0'
         for i in (3, 2, 1, 0):
             lay = dec_l[i]
             d = lay['desc']
             h, w = C.out_size(d)
             y = lay['y']
-            gz, gz16 = new(y), tw(y)
             pw, pb, pfw, pfb = (po_dec + 4 * i + j for j in range(4))
-            C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
-                       grads[pfw], grads[pfb], B, h, w, d.Cout, gx16=gz16)
+            head_w = None
+            if head_in_dgrad:
+                # the finer stage's data gradient already wrote d/d(pre-activation)
+                # of this stage (head path and act' in its epilogue): only the
+                # head's own weight / bias gradient is left, off the critical chain
+                gz, gz16 = g_x, None
+
+                def head_w(y=y, wf=params[pfw], g=g_f, gw=grads[pfw], gb=grads[pfb],
+                           h=h, w=w, c=d.Cout):
+                    C.head_bwd(y, wf, g, None, None, act, None, gw, gb, B, h, w, c)
+            else:
+                gz, gz16 = new(y), tw(y)
+                C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
+                           grads[pfw], grads[pfb], B, h, w, d.Cout, gx16=gz16)
             fold = lay.get('fold')
             if fold is not None:
                 fold = dict(fold, w=params[pw], head_idx=po_dec + 4 * (i - 1) + 2)
-            wgrad(d, gz, grads[pw], grads[pb], ('dec', i), gz16, fold)
+            wgrad(d, gz, grads[pw], grads[pb], ('dec', i), gz16, fold, first=head_w)
             srcs = lay['srcs']
             g_in = new(srcs[0][0])
             g_e = new(srcs[1][0])
             dsts = [dict(p=g_in), dict(p=g_e)]
+            head_in_dgrad = False
             if i == 0:
                 # x = r (last residual output): single consumer -> its dz,
                 # which the residual chain's data gradients read next
@@ -419,6 +435,14 @@ class _PredictorFn(torch.autograd.Function):
                 # cat[x, skip] with the folded weights: g_in already holds the
                 # path through the flow head, which then sees the loss gradient only
                 g_fprev = gflows[i - 1]
+                wf_prev = params[po_dec + 4 * (i - 1) + 2]
+                if (fuse_heads and C.dgrad_fuses_head(fold['desc'])
+                        and wf_prev.data_ptr() % 16 == 0):
+                    # ... and the head below goes into this data gradient's epilogue
+                    # (dvsof_grad_dst_t.head_w): g_in leaves as dec[i-1]'s dz
+                    head_in_dgrad = True
+                    dsts[0].update(head_w=wf_prev, head_gflow=g_fprev,
+                                   actsrc=asrc(dec_l[i - 1]))
                 C.conv_dgrad(fold['desc'], fold['w_dg'], gz, dsts, act,
                              weight16=fold['w_dg16'], gout16=gz16)
             else:

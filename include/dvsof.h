@@ -395,6 +395,16 @@ typedef struct {
     const float *actsrc; /* optional: p *= act'(actsrc), the producer's y
                             (ReLU) or z (Mish): yields its dz directly */
     void *p16;           /* optional bf16 twin of p, written (mode 3) */
+    /* optional, only where dvsof_conv2d_dgrad_fuses_head(desc) says so (the
+     * nine-product data gradient, csrc/dgrad_min.hip): the flow head that hangs
+     * on this source is folded into the epilogue,
+     *   p = (result + addends + head_w[0][c] gflow[b][0][y][x] + head_w[1][c] gflow[b][1][y][x]) * act'(actsrc)
+     * head_w [2][C] (the head's 1x1 weights), head_gflow [B][2][H][W] planar (the
+     * flow's loss gradient): what dvsof_flow_head_bwd computes as gx, without
+     * the pass over the tensor in between (the head's own weight gradient:
+     * dvsof_flow_head_bwd with gx == NULL).  DVSOF_EINVAL on any other kernel. */
+    const float *head_w;
+    const float *head_gflow;
 } dvsof_grad_dst_t;
 
 /*
@@ -404,6 +414,9 @@ typedef struct {
  * plain layer the tap-flipped transpose [Ctot][ksize][ksize][Cout]).  dst[i].p == NULL skips nothing (all sources
  * are computed together); pass a scratch buffer if a gradient is not needed.
  */
+/* 1 when the data gradient of this layer accepts dvsof_grad_dst_t.head_w /
+ * head_gflow (shape test alone; see above) */
+int dvsof_conv2d_dgrad_fuses_head(const dvsof_conv_desc_t *desc);
 int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *desc, const float *weight_t,
                        const float *gout, const dvsof_grad_dst_t *dst,
                        int bwd_act, void *stream);

@@ -477,6 +477,30 @@ def test_decoder_dgrad_nine_product_form_epilogue():
                                            actsrc=nhwc(ysrc)), dict(p=bufs[1])], C.ACT_RELU)
     close(from_nhwc(bufs[0]), want0)
     close(from_nhwc(bufs[1]), xs[1].grad)
+    # a flow head on member 0 folded into the epilogue (dvsof_grad_dst_t.head_w):
+    # + W_h^T g_flow ahead of act'; the head's own weight gradient with gx=None
+    assert C.dgrad_fuses_head(desc)
+    wh, gf = torch.randn(2, 128) / 8, torch.randn(2, 2, 16, 32)
+    want_h = (xs[0].grad + a1 + torch.einsum('kc,bkyx->bcyx', wh, gf)) * (ysrc > 0).float()
+    C.conv_dgrad(desc, wt, nhwc(gz), [dict(p=bufs[0], addend=nhwc(a1), actsrc=nhwc(ysrc),
+                                           head_w=wh.cuda(), head_gflow=gf.cuda()),
+                                      dict(p=bufs[1])], C.ACT_RELU)
+    close(from_nhwc(bufs[0]), want_h)
+    close(from_nhwc(bufs[1]), xs[1].grad)
+    dw, db = torch.empty(2, 128, device='cuda'), torch.empty(2, device='cuda')
+    C.head_bwd(nhwc(ysrc), wh.cuda(), gf.cuda(), None, None, C.ACT_RELU, None, dw, db,
+               2, 16, 32, 128)
+    close(dw, torch.einsum('bkyx,bcyx->kc', gf, ysrc))
+    close(db, gf.sum((0, 2, 3)))
+    # ... and refused where the kernel is another one (here: stride 1, no up-sampling)
+    case2 = dict(B=1, H=8, W=16, src=[(64, 'nhwc')], Cout=64, up=False)
+    C2, xs2, w2, b2, desc2, act2, o2 = build(case2, seed=6)
+    assert not C.dgrad_fuses_head(desc2)
+    _, wt2 = C.prepare(desc2, wphys(w2), True)
+    with pytest.raises(Exception):
+        C.conv_dgrad(desc2, wt2, torch.zeros(1, 8, 16, 64, device='cuda'),
+                     [dict(p=torch.empty(1, 8, 16, 64, device='cuda'), head_w=wh.cuda(),
+                           head_gflow=gf.cuda())], C.ACT_RELU)
 
 
 @pytest.mark.parametrize('Cc,act', [(32, 'relu'), (256, 'relu'), (64, 'mish')])
