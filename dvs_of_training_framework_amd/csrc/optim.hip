@@ -17,7 +17,10 @@ struct AdamArgs {
     int amsgrad;
 };
 
-constexpr int CHUNK = 4096;  // elements per workgroup
+#ifndef DVSOF_ADAM_CHUNK
+#define DVSOF_ADAM_CHUNK 1024   // (measured in the step: 1024 3150, 2048 3133, 4096 3118, 8192 3091 samples/s)
+#endif
+constexpr int CHUNK = DVSOF_ADAM_CHUNK;  // elements per workgroup
 
 // op order of torch.optim.adam._single_tensor_adam (decoupled weight decay)
 __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float &vm,

@@ -10,6 +10,7 @@
 #   hbm [ENV=VAL ...]                 voxeliser / loss call paths at the BASELINE.json sizes
 #   lossprobe B H W bits...           loss path under the probe build's DVSOF_LOSS_DBG bits
 #   timeline [bench args]             rocprofv3 kernel trace of a short run -> one step per queue
+#   feedtrace [wire|compact]          kernel + memory-copy trace of the train loop fed from host memory
 #   nodes [bench args]                the executor's plan (lane, stand-alone us of every kernel)
 #   collect <stage>                   everything under profiles/<round>/: tools/collect_profiles.sh +
 #                                     HBM-path PMC passes + plan + timeline + loopback / 1-rank-group runs
@@ -52,6 +53,13 @@ timeline)
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-modes --no-roofline --no-train-loop "$@" > $O/trace.log 2>&1 || { tail -3 $O/trace.log; exit 1; }
   cd $R; python3 tools/timeline.py $(find $O/t -name "*kernel_trace.csv") > $O/timeline.txt; rm -rf $O/t; head -4 $O/timeline.txt ;;
+feedtrace)
+  leg=${1:-wire}
+  timeout -k 10 300 python3 tools/feed_trace.py $leg 90 > $O/plain_$leg.json 2> $O/plain.err || { tail -3 $O/plain.err; exit 1; }
+  cat $O/plain_$leg.json; echo
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/t -o t -- python3 $R/tools/feed_trace.py $leg 45 > $O/trace.log 2>&1 || { tail -3 $O/trace.log; exit 1; }
+  cd $R; python3 tools/feed_timeline.py $O/t > $O/feed_$leg.txt; rm -rf $O/t; head -40 $O/feed_$leg.txt ;;
 nodes)
   python3 tools/exec_nodes.py "$@" | tee $O/exec_nodes.txt | tail -3 ;;
 collect)
