@@ -873,7 +873,19 @@ def main():
                'exchange stream)' if ex.marks else ''))
     if not a.no_roofline:
         h.suspend_graph()       # per-launch HIP events need eager launches
-        roof = measure_roofline(h, dt / a.steps * 1e3)   # every rank runs the same steps
+        # The per-launch measurement needs no exchange: under data parallelism it runs with the
+        # reducer detached (replicas drift apart from here on -- the timed region is over), so
+        # that no rank waits for another in it and a failure stays that rank's own.
+        reducer, h.reducer = h.reducer, None
+        h.model.predictor.reducer = None
+        try:
+            roof = measure_roofline(h, dt / a.steps * 1e3)
+        except Exception as e:      # noqa: BLE001 -- the headline above stands without it
+            if world == 1:
+                raise
+            roof = {'error': f'{type(e).__name__}: {e}'}
+        h.reducer = reducer
+        h.model.predictor.reducer = reducer
         if rank == 0:
             out['roofline'] = roof
     if rank == 0 and world == 1 and a.dtype == 'f32' and not a.no_other_modes:

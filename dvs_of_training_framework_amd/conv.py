@@ -26,7 +26,9 @@ class ConvDesc(ctypes.Structure):
                 ('pad', _i), ('Cout', _i), ('act', _i), ('mfma', _i),
                 ('scratch', _vp), ('scratch_bytes', _sz),
                 ('winograd_input', _vp), ('y16', _vp), ('w16', _vp),
-                ('gout16', _vp), ('flags', _i), ('bias_cls', _vp)]
+                ('gout16', _vp), ('flags', _i), ('bias_cls', _vp),
+                ('winograd_pre', _vp), ('winograd_next', _vp),
+                ('winograd_next_gout', _vp), ('winograd_gout', _vp)]
 
 
 class GradDst(ctypes.Structure):
@@ -70,6 +72,7 @@ _lib.register('dvsof_flow_fold_grads', _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _
                                             _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp])
 WGRAD_SKIP_FLAT = 1
 _lib.register('dvsof_conv2d_winograd_tile', _i, [_P(ConvDesc), _i])
+_lib.register('dvsof_conv2d_winograd_chain', _i, [_P(ConvDesc), _i])
 
 
 MFMA_F32, MFMA_BF16, MFMA_BF16X3, MFMA_BF16_TWINS = 0, 1, 2, 3
@@ -176,12 +179,40 @@ def _scratch(desc, device):
     return t
 
 
+def winograd_chain(desc, kind):
+    """Can this layer's forward (kind 0) / data gradient (kind 1) also write
+    the Winograd forms of its consumer (``wino_next`` / ``wino_next_gout``)?"""
+    return bool(_lib.lib().dvsof_conv2d_winograd_chain(ctypes.byref(desc), kind))
+
+
+def winograd_tile(desc, kind):
+    """0 | 2 | 4: Winograd output tile of the forward (kind 0), data gradient
+    (1) or weight gradient (2) of this layer (dvsof_conv2d_winograd_tile)."""
+    return _lib.lib().dvsof_conv2d_winograd_tile(ctypes.byref(desc), kind)
+
+
+def winograd_form(desc, channels, device):
+    """Buffer of one F(4x4) form [36][tiles][channels] of this layer's frame."""
+    tiles = desc.B * (desc.H // 4) * (desc.W // 4)
+    return torch.empty(36 * tiles * channels, dtype=torch.float32, device=device)
+
+
+def _chain(desc, pre=None, nxt=None, nxt_gout=None, gout=None):
+    desc.winograd_pre = _lib.ptr(pre)
+    desc.winograd_next = _lib.ptr(nxt)
+    desc.winograd_next_gout = _lib.ptr(nxt_gout)
+    desc.winograd_gout = _lib.ptr(gout)
+
+
 def conv_fwd(desc, weight, bias, device, residual=None, want_z=False,
-             keep_input_transform=False, weight16=None, bias_cls=None):
+             keep_input_transform=False, weight16=None, bias_cls=None,
+             wino_pre=None, wino_next=None):
     """-> y [B,Ho,Wo,Cout] (NHWC buffer), z or None.  In mode 3
     (MFMA_BF16_TWINS) ``desc._y16`` is y's bf16 twin afterwards.
     keep_input_transform: a Winograd layer's scratch (it starts with the
-    transformed input) stays attached to ``desc`` for conv_wgrad."""
+    transformed input) stays attached to ``desc`` for conv_wgrad.
+    wino_pre / wino_next: forms shared along a chain of Winograd layers
+    (dvsof_conv_desc_t.winograd_pre / winograd_next; winograd_form buffers)."""
     ho, wo = out_size(desc)
     y = torch.empty(desc.B, ho, wo, desc.Cout, dtype=torch.float32,
                     device=device)
@@ -191,11 +222,14 @@ def conv_fwd(desc, weight, bias, device, residual=None, want_z=False,
     desc.w16 = _lib.ptr(weight16)
     desc.bias_cls = _lib.ptr(bias_cls)
     ws = _scratch(desc, device)     # noqa: F841  (alive across the call)
+    _chain(desc, pre=wino_pre, nxt=wino_next)
     _lib.check(_lib.lib().dvsof_conv2d_fwd(
         ctypes.byref(desc), weight.data_ptr(), _lib.ptr(bias),
         _lib.ptr(residual), y.data_ptr(), _lib.ptr(z), _lib.stream()),
         'dvsof_conv2d_fwd')
-    desc._wino_input = ws if keep_input_transform else None
+    _chain(desc)
+    desc._wino_input = (wino_pre if wino_pre is not None else ws) \
+        if keep_input_transform else None
     return y, z
 
 
@@ -261,8 +295,9 @@ def flip_transpose(weight, Cout, ksize, Ctot):
 
 
 def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE, weight16=None,
-               gout16=None):
-    """dsts: list of dict(p=, addend=, addend2=, actsrc=[, p16=]) per source."""
+               gout16=None, wino_pre=None, wino_next=None, wino_next_gout=None):
+    """dsts: list of dict(p=, addend=, addend2=, actsrc=[, p16=]) per source.
+    wino_*: forms shared along a chain of Winograd layers (conv_fwd)."""
     arr = (GradDst * len(dsts))()
     for i, d in enumerate(dsts):
         arr[i].p = d['p'].data_ptr()
@@ -275,9 +310,11 @@ def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE, weight16=None,
     desc.w16 = _lib.ptr(weight16)
     desc.gout16 = _lib.ptr(gout16)
     ws = _scratch(desc, gout.device)     # noqa: F841
+    _chain(desc, pre=wino_pre, nxt=wino_next, nxt_gout=wino_next_gout)
     _lib.check(_lib.lib().dvsof_conv2d_dgrad(
         ctypes.byref(desc), weight_t.data_ptr(), gout.data_ptr(), arr,
         bwd_act, _lib.stream()), 'dvsof_conv2d_dgrad')
+    _chain(desc)
 
 
 def flow_fold_weights(w, Cout, Ctot, cx_off, Cx, cf_off, wh):
@@ -312,7 +349,8 @@ def flow_fold_grads(dW, w, Cout, Ctot, cx_off, Cx, cf_off, wh, bh, db_conv, g,
         _lib.stream()), 'dvsof_flow_fold_grads')
 
 
-def conv_wgrad(desc, gout, dweight, dbias, gout16=None, skip_flat=False):
+def conv_wgrad(desc, gout, dweight, dbias, gout16=None, skip_flat=False,
+               wino_gout=None):
     """gout16: bf16 twin of gout (mode 3): with the sources' twins the
     vector members' weight gradient streams bf16 through LDS.  skip_flat:
     the narrow planar members' columns are left to flow_fold_grads."""
@@ -323,10 +361,12 @@ def conv_wgrad(desc, gout, dweight, dbias, gout16=None, skip_flat=False):
                      device=gout.device)
     kept = getattr(desc, '_wino_input', None)
     desc.winograd_input = kept.data_ptr() if kept is not None else None
+    _chain(desc, gout=wino_gout)
     _lib.check(_lib.lib().dvsof_conv2d_wgrad(
         ctypes.byref(desc), gout.data_ptr(), dweight.data_ptr(),
         _lib.ptr(dbias), ws.data_ptr(), ws.numel() * 4, _lib.stream()),
         'dvsof_conv2d_wgrad')
+    _chain(desc)
 
 
 def head_fwd(x, w, bias, B, H, W, C):
@@ -382,3 +422,28 @@ def act_bwd(dy, actsrc, act, out=None):
         dy.data_ptr(), actsrc.data_ptr(), act, out.data_ptr(), dy.numel(),
         _lib.stream()), 'dvsof_act_bwd')
     return out
+
+
+# ---- timing experiment (DVSOF_STALE_FORMS=1; results are WRONG after the first step): every
+# weight form is made once and reused -- what the step would cost if the forms were free
+import os as _os
+if _os.environ.get('DVSOF_STALE_FORMS') == '1':
+    def _memo(fn, key):
+        cache = {}
+
+        def inner(*a, **k):
+            kk = key(*a, **k)
+            if kk not in cache:
+                cache[kk] = fn(*a, **k)
+            return cache[kk]
+        return inner
+
+    def _dkey(d):
+        return (d.nsrc, tuple(d.src[i].C for i in range(d.nsrc)), d.B, d.H, d.W, d.upsample,
+                d.stride, d.Cout, d.mfma)
+    prepare = _memo(prepare, lambda d, w, dg, phase_weights=None, want16=False:
+                    (_dkey(d), w.data_ptr(), dg, phase_weights is not None and phase_weights.data_ptr(), want16))
+    flow_fold_weights = _memo(flow_fold_weights, lambda w, *a: (w.data_ptr(),) + tuple(
+        x if isinstance(x, int) else x.data_ptr() for x in a))
+    flow_fold_bias = _memo(flow_fold_bias, lambda w, *a: (w.data_ptr(),) + tuple(
+        x if isinstance(x, int) else (x.data_ptr() if x is not None else 0) for x in a))

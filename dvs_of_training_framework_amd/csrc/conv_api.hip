@@ -17,11 +17,12 @@ int wino_components(int B, int H, int W, int mfma);
 size_t wino_scratch_floats(int B, int H, int W, int C, int N, int mfma);
 int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int B, int H, int W, int mfma,
                  hipStream_t st);
-int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st);
+int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, const WinoChain &ch, hipStream_t st);
+bool wino_chain_ok(int B, int H, int W, int N, int mfma);
 int wino_wgrad_tile(int B, int H, int W, int mfma);
 size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N, int mfma);
 int wino_tile(int B, int H, int W, int mfma);
-int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *gout, float *dW, float *dbias, int B,
+int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *Z_in, const float *gout, float *dW, float *dbias, int B,
                       int H, int W, int C, int N, int mfma_bf16, float *ws, size_t ws_floats,
                       hipStream_t st);
 
@@ -807,8 +808,12 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
         P.dst[0].ph_y = Wo * d->Cout;
         P.dst[0].ph_x = d->Cout;
     }
-    if (is_wino(d))   // `weight` is the prepared U[16][Cout][Ctot]
-        return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
+    if (is_wino(d)) {  // `weight` is the prepared U[16][Cout][Ctot]
+        if (d->winograd_next_gout) return DVSOF_EINVAL;     // a data gradient's option
+        const WinoChain ch = {d->winograd_pre, d->winograd_next, nullptr};
+        return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), ch, as_stream(stream));
+    }
+    if (d->winograd_pre || d->winograd_next || d->winograd_next_gout) return DVSOF_EINVAL;
     if (is_min9(d)) {   // `weight` is the prepared Wt[9][Cout][Ctot]
         t_last_patch[0] = 2;
         return fwd_min_launch(P, as_stream(stream));
@@ -932,8 +937,11 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         t_last_patch[1] = 2;
         return dgrad_min_launch(P, as_stream(stream));
     }
-    if (is_wino(d))   // weight_t is the prepared U'[16][Ctot][Cout]
-        return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), as_stream(stream));
+    if (is_wino(d)) {  // weight_t is the prepared U'[16][Ctot][Cout]
+        const WinoChain ch = {d->winograd_pre, d->winograd_next, d->winograd_next_gout};
+        return wino_launch(P, (float *)d->scratch, d->scratch_bytes / sizeof(float), ch, as_stream(stream));
+    }
+    if (d->winograd_pre || d->winograd_next || d->winograd_next_gout) return DVSOF_EINVAL;
     return gconv_launch(P, 0, as_stream(stream));
 }
 
@@ -1038,7 +1046,9 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
         const int mf = d->mfma == 2 ? 2 : 0;
         const float *v_in = wino_tile(d->B, d->H, d->W, mf) == wino_wgrad_tile(d->B, d->H, d->W, mf)
                                 ? d->winograd_input : nullptr;
-        return wino_wgrad_launch(make_src(d->src[0].p, d->src[0].C, d->src[0].layout, d->H, d->W), v_in,
+        // ... and the gradient form of gout, when the data gradient that produced gout made it
+        const float *z_in = wino_wgrad_tile(d->B, d->H, d->W, mf) == 4 ? d->winograd_gout : nullptr;
+        return wino_wgrad_launch(make_src(d->src[0].p, d->src[0].C, d->src[0].layout, d->H, d->W), v_in, z_in,
                                  gout, dweight, dbias, d->B, d->H, d->W, Ctot, d->Cout, mf, (float *)ws,
                                  ws_bytes / sizeof(float), as_stream(stream));
     }
@@ -1189,6 +1199,15 @@ int dvsof_conv2d_winograd_tile(const dvsof_conv_desc_t *d, int kind)
     const int mfma = d->mfma == 2 ? 2 : 0;
     if (kind == 2) return is_wino_wgrad(d) ? wino_wgrad_tile(d->B, d->H, d->W, mfma) : 0;
     return wino_tile(d->B, d->H, d->W, mfma);
+}
+
+// 1: this layer's forward (kind 0) / data gradient (kind 1) is a Winograd evaluation whose output
+// transform can also write the consumer's forms (winograd_next / winograd_next_gout)
+int dvsof_conv2d_winograd_chain(const dvsof_conv_desc_t *d, int kind)
+{
+    int Ctot, Ho, Wo;
+    if (!desc_ok(d, Ctot, Ho, Wo) || !is_wino(d) || (kind != 0 && kind != 1)) return 0;
+    return wino_chain_ok(d->B, d->H, d->W, kind == 0 ? d->Cout : Ctot, d->mfma == 2 ? 2 : 0) ? 1 : 0;
 }
 
 // 2 when the LDS-DMA (v2) kernel serves this problem's vector members, else 1;

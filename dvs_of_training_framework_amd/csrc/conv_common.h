@@ -84,6 +84,14 @@ struct GConvParams {
                         // 128 = every K step re-reads chunk 0 (cache-resident footprint)
 };
 
+// winograd.hip: forms shared between consecutive Winograd layers of one frame (dvsof_conv_desc_t.
+// winograd_pre / winograd_next / winograd_next_gout)
+struct WinoChain {
+    const float *v_pre;   // this call's transformed input, made by its producer (skip the input transform)
+    float *v_next;        // also write B^T y B of this call's output (the consumer's transformed input)
+    float *z_next;        // also write A y A^T (the gradient form of the weight gradient that reads y as gout)
+};
+
 // Weight-gradient problem (wgrad.hip)
 struct WGradParams {
     GSrc src[3];

@@ -354,6 +354,134 @@ __global__ __launch_bounds__(NT) void wino_output_kernel(const float *__restrict
     }
 }
 
+// The output transform of a layer whose result feeds ANOTHER Winograd layer of the same frame
+// (the residual chain: forward y -> next convolution; data gradient dz -> the data gradient
+// and the weight gradient below), with the consumer's transforms made from the workgroup's own
+// copy of the tile it just wrote -- one launch and one pass over y instead of three:
+//     y  = epilogue(A^T Mb A)                      exactly wino_output_kernel's
+//     Vn = B^T y B   [NG][T][N]                    the consumer's wino_input_kernel   (or null)
+//     Zn = A y A^T   [NG][T][N]                    its weight gradient's wino_gout_kernel (or null)
+// B^T y B needs a 1-pixel halo, i.e. the neighbouring tiles' outputs: a workgroup owns a WHOLE
+// image x 16 channels (thread = (tile, channel); frames of <= 64 tiles), stages y in LDS with
+// a zero border and transforms from there.  Bitwise the same y, Vn, Zn as the three kernels.
+constexpr int WC_CG = 16;      // channels per workgroup
+template <int F>
+__global__ __launch_bounds__(1024) void wino_chain_kernel(const float *__restrict__ Mb, const WinoOut O,
+                                                          const WinoGeom G, float *__restrict__ Vn,
+                                                          float *__restrict__ Zn)
+{
+    constexpr int NA = Wino<F>::NA;
+    extern __shared__ float ybuf[];     // [(H + 2)][(W + 2)][WC_CG]
+    const int LWp = G.W + 2;
+    const int tid = threadIdx.x, cl = tid % WC_CG, tl = tid / WC_CG;
+    const int n = blockIdx.x * WC_CG + cl, b = blockIdx.y;
+    const int tx = tl % G.Tw, ty = tl / G.Tw;
+    const int t = b * (G.Th * G.Tw) + tl;
+    // zero border of the staged frame
+    for (int i = tid; i < 2 * (G.W + 2 + G.H) * WC_CG; i += blockDim.x) {
+        const int c = i % WC_CG, q = i / WC_CG;
+        int yy, xx;
+        if (q < G.W + 2) { yy = 0; xx = q; }
+        else if (q < 2 * (G.W + 2)) { yy = G.H + 1; xx = q - (G.W + 2); }
+        else if (q < 2 * (G.W + 2) + G.H) { yy = q - 2 * (G.W + 2) + 1; xx = 0; }
+        else { yy = q - 2 * (G.W + 2) - G.H + 1; xx = G.W + 1; }
+        ybuf[(yy * LWp + xx) * WC_CG + c] = 0.f;
+    }
+    const size_t plane = (size_t)G.T * O.N;
+    const float *mp = Mb + (size_t)t * O.N + n;
+    float s[F][NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {   // s[.][j] = A^T m[.][j]
+        float m[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) m[i] = mp[(size_t)(i * NA + j) * plane];
+        float o[F];
+        Wino<F>::at(m, o);
+#pragma unroll
+        for (int i = 0; i < F; ++i) s[i][j] = o[i];
+    }
+    const float bv = O.bias ? O.bias[n] : 0.f;
+    const size_t o0 = (size_t)b * O.D.sb + (size_t)(F * ty) * O.D.sy + (size_t)(F * tx) * O.D.sx + n;
+    float yv[F][F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        float v[F];
+        Wino<F>::at(s[i], v);
+        size_t o[F];
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            o[j] = o0 + (size_t)i * O.D.sy + (size_t)j * O.D.sx;
+            v[j] += bv;
+        }
+        float a1[F], a2[F], as[F];
+        if (O.D.addend)
+#pragma unroll
+            for (int j = 0; j < F; ++j) a1[j] = O.D.addend[o[j]];
+        if (O.D.addend2)
+#pragma unroll
+            for (int j = 0; j < F; ++j) a2[j] = O.D.addend2[o[j]];
+        if (O.D.actsrc)
+#pragma unroll
+            for (int j = 0; j < F; ++j) as[j] = O.D.actsrc[o[j]];
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            if (O.D.addend) v[j] += a1[j];
+            if (O.D.addend2) v[j] += a2[j];
+            if (O.D.actsrc) v[j] *= act_bwd(as[j], O.bwd_act);
+        }
+        if (O.zout)
+#pragma unroll
+            for (int j = 0; j < F; ++j) O.zout[o[j]] = v[j];
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const float y = act_fwd(v[j], O.act);
+            O.D.p[o[j]] = y;
+            yv[i][j] = y;
+            ybuf[((F * ty + i + 1) * LWp + F * tx + j + 1) * WC_CG + cl] = y;
+        }
+    }
+    if (Zn) {   // A y A^T of the tile itself (wino_gout_kernel)
+        float u[NA][F];
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const float d[F] = {yv[0][j], yv[1][j], yv[2][j], yv[3][j]};
+            float o[NA];
+            Wino<F>::a(d, o);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) u[i][j] = o[i];
+        }
+        float *zo = Zn + (size_t)t * O.N + n;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            float v[NA];
+            Wino<F>::a(u[i], v);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) zo[(size_t)(i * NA + j) * plane] = v[j];
+        }
+    }
+    if (!Vn) return;
+    __syncthreads();
+    float u[NA][NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {   // column j of the patch (wino_input_kernel)
+        float d[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) d[i] = ybuf[((F * ty + i) * LWp + F * tx + j) * WC_CG + cl];
+        float o[NA];
+        Wino<F>::bt(d, o);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) u[i][j] = o[i];
+    }
+    float *vo = Vn + (size_t)t * O.N + n;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float v[NA];
+        Wino<F>::bt(u[i], v);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) vo[(size_t)(i * NA + j) * plane] = v[j];
+    }
+}
+
 // Z[g][t][n] = (A dY A^T)[g], dY = the tile's F x F output gradients (dense NHWC gout)
 template <int F, int NT, int VW>
 __global__ __launch_bounds__(NT) void wino_gout_kernel(const float *__restrict__ gout, const WinoGeom G,
@@ -486,6 +614,17 @@ bool wino_eligible_shape(int nsrc, int layout_nhwc, int C, int N, int B, int H, 
     return wino_tile(B, H, W, mfma == 2 ? 2 : 0) != 0;
 }
 
+// Can the output transform of a Winograd evaluation at this frame also make the consumer's
+// forms (wino_chain_kernel)?  F(4x4) form, whole image per workgroup: <= 64 tiles per image, a
+// multiple of 4 (whole waves), the staged frame within 64 KB of LDS.  DVSOF_NO_WINO_CHAIN=1: off
+bool wino_chain_ok(int B, int H, int W, int N, int mfma)
+{
+    static const bool off = getenv("DVSOF_NO_WINO_CHAIN") != nullptr;
+    if (off || wino_tile(B, H, W, mfma) != 4 || (N % WC_CG)) return false;
+    const int tiles = (H / 4) * (W / 4);
+    return tiles <= 64 && (tiles % 4) == 0 && (size_t)(H + 2) * (W + 2) * WC_CG * 4 <= 64 * 1024;
+}
+
 size_t wino_scratch_floats(int B, int H, int W, int C, int N, int mfma)
 {
     const int f = wino_tile(B, H, W, mfma);
@@ -515,18 +654,20 @@ int wino_prepare(const float *weight, float *U, float *Ut, int N, int C, int B, 
 }
 
 template <int F>
-static int wino_launch_f(const GConvParams &P, float *scratch, hipStream_t st)
+static int wino_launch_f(const GConvParams &P, float *scratch, const WinoChain &ch, hipStream_t st)
 {
     constexpr int NA = Wino<F>::NA, NG = NA * NA;
     constexpr int NT = 256;
     const int C = P.Cin_tot, N = P.N;
     WinoGeom G = {P.B, P.Hv, P.Wv, P.Hv / F, P.Wv / F, P.B * (P.Hv / F) * (P.Wv / F)};
-    float *V = scratch, *Mb = scratch + (size_t)NG * G.T * C;
+    // (ch.v_pre: the producer's output transform already made this call's transformed input)
+    float *V = ch.v_pre ? const_cast<float *>(ch.v_pre) : scratch, *Mb = scratch + (size_t)NG * G.T * C;
 
     // few tiles: one channel per thread (4x the threads; these launches are latency bound)
     static const int vw_env = env_int("DVSOF_WINO_VW", 0);
     const bool scalar = vw_env ? vw_env == 1 : (long long)G.T * (C > N ? C : N) / 4 < 256 * 256;
-    if (scalar)
+    if (ch.v_pre) {
+    } else if (scalar)
         hipLaunchKernelGGL((wino_input_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * C, NT)), dim3(NT), 0,
                            st, P.src[0], G, V);
     else
@@ -568,6 +709,18 @@ static int wino_launch_f(const GConvParams &P, float *scratch, hipStream_t st)
     if (rc) return rc;
 
     WinoOut O = {P.dst[0], P.bias, P.zout, P.act, P.bwd_act, N};
+    if (ch.v_next || ch.z_next) {
+        if constexpr (F == 4) {
+            if (!wino_chain_ok(P.B, P.Hv, P.Wv, N, P.mfma_bf16)) return DVSOF_EINVAL;
+            const size_t lds = (size_t)(G.H + 2) * (G.W + 2) * WC_CG * sizeof(float);
+            hipLaunchKernelGGL((wino_chain_kernel<4>), dim3(N / WC_CG, G.B), dim3(G.Th * G.Tw * WC_CG), lds, st,
+                               (const float *)Mb, O, G, ch.v_next, ch.z_next);
+            DVSOF_LAUNCH_CHECK();
+            return DVSOF_OK;
+        } else {
+            return DVSOF_EINVAL;
+        }
+    }
     if (scalar)
         hipLaunchKernelGGL((wino_output_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * N, NT)), dim3(NT), 0,
                            st, (const float *)Mb, O, G);
@@ -580,7 +733,7 @@ static int wino_launch_f(const GConvParams &P, float *scratch, hipStream_t st)
 
 // P: the direct problem (3x3, stride 1, pad 1, one NHWC source, one destination)
 // with P.W = U[NG][N][C].
-int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hipStream_t st)
+int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, const WinoChain &ch, hipStream_t st)
 {
     const int C = P.Cin_tot, N = P.N;
     if (P.nsrc != 1 || P.ndst != 1 || P.src[0].flat || P.src[0].sc != 1 || P.dst[0].sc != 1 ||
@@ -590,7 +743,7 @@ int wino_launch(const GConvParams &P, float *scratch, size_t scratch_floats, hip
         return DVSOF_ENOSPACE;
     const int f = wino_tile(P.B, P.Hv, P.Wv, P.mfma_bf16);
     if (f == 0) return DVSOF_EINVAL;
-    return f == 4 ? wino_launch_f<4>(P, scratch, st) : wino_launch_f<2>(P, scratch, st);
+    return f == 4 ? wino_launch_f<4>(P, scratch, ch, st) : wino_launch_f<2>(P, scratch, ch, st);
 }
 
 // ---- weight gradient
@@ -636,14 +789,15 @@ size_t wino_wgrad_workspace_floats(int B, int H, int W, int C, int N, int mfma)
 }
 
 template <int F>
-static int wino_wgrad_f(const GSrc &X, const float *V_in, const float *gout, float *dW, float *dbias,
-                        int B, int H, int W, int C, int N, int mfma_bf16, float *ws, hipStream_t st)
+static int wino_wgrad_f(const GSrc &X, const float *V_in, const float *Z_in, const float *gout, float *dW,
+                        float *dbias, int B, int H, int W, int C, int N, int mfma_bf16, float *ws, hipStream_t st)
 {
     constexpr int NA = Wino<F>::NA, NG = NA * NA;
     constexpr int NT = 256;
     WinoGeom G = {B, H, W, H / F, W / F, B * (H / F) * (W / F)};
     const int S = wino_wgrad_splits(NG, G.T, N, C);
-    float *Vws = ws, *Z = Vws + (size_t)NG * G.T * C, *dU = Z + (size_t)NG * G.T * N;
+    float *Vws = ws, *Zws = Vws + (size_t)NG * G.T * C, *dU = Zws + (size_t)NG * G.T * N;
+    const float *Z = Z_in ? Z_in : Zws;   // Z_in: the producer of gout already transformed it (wino_chain_kernel)
     float *bias_part = dU + (size_t)NG * S * N * C;
     const float *V = V_in ? V_in : Vws;   // V_in: the forward pass already transformed this input
 
@@ -654,15 +808,17 @@ static int wino_wgrad_f(const GSrc &X, const float *V_in, const float *gout, flo
             hipLaunchKernelGGL((wino_input_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * C, NT)), dim3(NT),
                                0, st, X, G, Vws);
         DVSOF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((wino_gout_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * N, NT)), dim3(NT), 0,
-                           st, gout, G, N, Z);
+        if (!Z_in)
+            hipLaunchKernelGGL((wino_gout_kernel<F, NT, 1>), dim3(nblocks((long long)G.T * N, NT)), dim3(NT), 0,
+                               st, gout, G, N, Zws);
     } else {
         if (!V_in)
             hipLaunchKernelGGL((wino_input_kernel<F, NT, 4>), dim3(nblocks((long long)G.T * (C / 4), NT)),
                                dim3(NT), 0, st, X, G, Vws);
         DVSOF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((wino_gout_kernel<F, NT, 4>), dim3(nblocks((long long)G.T * (N / 4), NT)),
-                           dim3(NT), 0, st, gout, G, N, Z);
+        if (!Z_in)
+            hipLaunchKernelGGL((wino_gout_kernel<F, NT, 4>), dim3(nblocks((long long)G.T * (N / 4), NT)),
+                               dim3(NT), 0, st, gout, G, N, Zws);
     }
     DVSOF_LAUNCH_CHECK();
 
@@ -710,14 +866,14 @@ static int wino_wgrad_f(const GSrc &X, const float *V_in, const float *gout, flo
     return DVSOF_OK;
 }
 
-int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *gout, float *dW, float *dbias, int B,
-                      int H, int W, int C, int N, int mfma_bf16, float *ws, size_t ws_floats,
+int wino_wgrad_launch(const GSrc &X, const float *V_in, const float *Z_in, const float *gout, float *dW,
+                      float *dbias, int B, int H, int W, int C, int N, int mfma_bf16, float *ws, size_t ws_floats,
                       hipStream_t st)
 {
     if (X.flat || X.sc != 1 || X.C != C) return DVSOF_EINVAL;
     const int f = wino_wgrad_tile(B, H, W, mfma_bf16);
     if (f == 0) return DVSOF_EINVAL;
     if (!ws || ws_floats < wino_wgrad_workspace_floats(B, H, W, C, N, mfma_bf16)) return DVSOF_ENOSPACE;
-    return f == 4 ? wino_wgrad_f<4>(X, V_in, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st)
-                  : wino_wgrad_f<2>(X, V_in, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st);
+    return f == 4 ? wino_wgrad_f<4>(X, V_in, Z_in, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st)
+                  : wino_wgrad_f<2>(X, V_in, Z_in, gout, dW, dbias, B, H, W, C, N, mfma_bf16, ws, st);
 }

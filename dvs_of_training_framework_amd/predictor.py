@@ -194,10 +194,19 @@ class _PredictorFn(torch.autograd.Function):
                 pre_ready.record(side)
         waited, waited16 = [False], [False]
 
+        chain = {'v': None}     # Winograd form a layer made for its consumer
+        # (Measured and not kept: the data-gradient weight forms issued late, beside the
+        # decoder's kernels instead of layer by layer beside the encoder / residual layers:
+        # 2.522-2.530 ms wherever they run -- the step is bound by total work, and the forms
+        # cost 63 us of it: 2.451 ms with stale forms, DVSOF_STALE_FORMS=1.)
+
         def run(srcs, h, w, cout, wgt, bias, stride=1, up=False,
-                residual=None):
+                residual=None, chained=(False, False)):
             """-> (y, y16): the layer's output and, in the bf16-twins mode,
-            its bf16 copy (written by the same kernel)."""
+            its bf16 copy (written by the same kernel).  chained = (its
+            producer / its consumer is a Winograd layer of the same frame:
+            the transformed input travels from output transform to GEMM,
+            dvsof_conv_desc_t.winograd_next)."""
             d = C.make_desc(srcs, B, h, w, cout, 3, stride, 1, up, act,
                             module.mfma)
             # prepared weights: sub-pixel phase kernels for the decoder,
@@ -251,9 +260,13 @@ class _PredictorFn(torch.autograd.Function):
                 w_fwd16 = raw16.get(id(wgt))
                 if w_fwd16 is None or w_fwd is not wgt:
                     w_fwd16 = C.to_bf16(w_fwd)
+            v_pre = chain['v'] if chained[0] else None
+            chain['v'] = C.winograd_form(d, cout, dev) \
+                if chained[1] and C.winograd_chain(d, 0) else None
             y, z = C.conv_fwd(d, w_fwd, bias, dev, residual, mish,
                               keep_input_transform=want_grad,
-                              weight16=w_fwd16)
+                              weight16=w_fwd16, wino_pre=v_pre,
+                              wino_next=chain['v'])
             L.append(dict(desc=d, y=y, z=z, srcs=srcs, w=wgt, w_dg=w_dg,
                           w_dg16=w_dg16, fold=fold))
             return y, d._y16
@@ -270,9 +283,9 @@ class _PredictorFn(torch.autograd.Function):
         r = e[3]
         for i in range(NUM_RES):
             t = run([(t_[0], 512, C.NHWC, t_[1]) for t_ in (r,)], h, w, 512,
-                    res[i][0], res[i][1])
+                    res[i][0], res[i][1], chained=(i > 0, True))
             r = run([(t[0], 512, C.NHWC, t[1])], h, w, 512, res[i][2],
-                    res[i][3], residual=r[0])
+                    res[i][3], residual=r[0], chained=(True, i + 1 < NUM_RES))
         # decoder
         flows, xx, cx, f, heads = [], r, 512, None, []
         for i in range(4):
@@ -354,14 +367,16 @@ class _PredictorFn(torch.autograd.Function):
         # weight gradient, ahead of it on the same stream.
         pending = []
 
-        def wgrad(desc, gz, gw, gb, unit, gz16=None, fold=None, first=None):
+        def wgrad(desc, gz, gw, gb, unit, gz16=None, fold=None, first=None,
+                  wino_gout=None):
             def body():
                 if first is not None:
                     first()
                 for job in pending:
                     job()
                 del pending[:]
-                C.conv_wgrad(desc, gz, gw, gb, gz16, skip_flat=fold is not None)
+                C.conv_wgrad(desc, gz, gw, gb, gz16, skip_flat=fold is not None,
+                             wino_gout=wino_gout)
                 if fold is None:
                     finish(unit)
                 else:
@@ -459,22 +474,45 @@ class _PredictorFn(torch.autograd.Function):
                 g_r = g_in
         # ---- residual blocks (g_r is already d/d pre-activation)
         gs, gs16 = g_r, g_r16
+        # Winograd forms along the chain (dvsof_conv_desc_t.winograd_next /
+        # winograd_next_gout): a data gradient's output transform also makes the
+        # transformed input of the data gradient below and the gradient form of
+        # the weight gradient below
+        v_pre = z_pre = None
+
+        def forms(producer, consumer):
+            if not C.winograd_chain(producer, 1):
+                return None, None
+            c_out = consumer.Cout
+            v = C.winograd_form(producer, c_out, dev)
+            z = C.winograd_form(producer, c_out, dev) \
+                if C.winograd_tile(consumer, 2) == 4 else None
+            keep.extend((v, z))
+            return v, z
         for i in reversed(range(NUM_RES)):
             l1, l2 = res_l[2 * i], res_l[2 * i + 1]
             pw1, pb1, pw2, pb2 = (po_res + 4 * i + j for j in range(4))
-            wgrad(l2['desc'], gs, grads[pw2], grads[pb2], ('res', i, 2), gs16)
+            wgrad(l2['desc'], gs, grads[pw2], grads[pb2], ('res', i, 2), gs16,
+                  wino_gout=z_pre)
             g_t, g_t16 = new(l1['y']), tw(l1['y'])
+            v_n, z_n = forms(l2['desc'], l1['desc'])
             C.conv_dgrad(l2['desc'], wt(l2), gs,
                          [dict(p=g_t, actsrc=asrc(l1), p16=g_t16)], act,
-                         weight16=l2['w_dg16'], gout16=gs16)
-            wgrad(l1['desc'], g_t, grads[pw1], grads[pb1], ('res', i, 1), g_t16)
+                         weight16=l2['w_dg16'], gout16=gs16, wino_pre=v_pre,
+                         wino_next=v_n, wino_next_gout=z_n)
+            v_pre, z_pre = v_n, z_n
+            wgrad(l1['desc'], g_t, grads[pw1], grads[pb1], ('res', i, 1), g_t16,
+                  wino_gout=z_pre)
             below = res_l[2 * i - 1] if i > 0 else enc_l[3]
             g_prev, g_prev16 = new(below['y']), tw(below['y'])
             dst = dict(p=g_prev, addend=gs, actsrc=asrc(below), p16=g_prev16)
             if i == 0:
                 dst['addend2'] = g_skip[3]      # dec.0's skip into e4
+            v_n, z_n = forms(l1['desc'], below['desc']) if i > 0 else (None, None)
             C.conv_dgrad(l1['desc'], wt(l1), g_t, [dst], act,
-                         weight16=l1['w_dg16'], gout16=g_t16)
+                         weight16=l1['w_dg16'], gout16=g_t16, wino_pre=v_pre,
+                         wino_next=v_n, wino_next_gout=z_n)
+            v_pre, z_pre = v_n, z_n
             keep.extend((gs16, g_t16))
             gs, gs16 = g_prev, g_prev16
         # ---- encoder.  Its weight gradients are issued on the MAIN stream after

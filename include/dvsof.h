@@ -330,6 +330,28 @@ typedef struct {
                             bottom 2) + (left 1 | right 2); row 0 (interior)
                             is not read.  The position-dependent share of a
                             folded constant member (dvsof_flow_fold_weights) */
+    /* Forms shared by CONSECUTIVE Winograd layers of one frame (the residual
+     * chain), all optional; dvsof_conv2d_winograd_chain(desc, kind) says whether
+     * this layer's forward / data gradient can write them (F(4x4) form, <= 64
+     * tiles per image), DVSOF_EINVAL otherwise.  A producer then makes the
+     * consumer's transforms in its own output transform (one launch and one pass
+     * over the tensor instead of three; same bits):
+     *   winograd_next       fwd / dgrad: also write the transformed input
+     *                       [36][T][channels of the output] of the layer that
+     *                       consumes this call's output (same B, H, W);
+     *   winograd_pre        fwd / dgrad: this call's transformed input as a
+     *                       producer wrote it -- the input transform is skipped
+     *                       (fwd: it is also what winograd_input names for the
+     *                       weight gradient);
+     *   winograd_next_gout  dgrad: also write the gradient form [36][T][C] of
+     *                       the output, for the weight gradient that takes it as
+     *                       gout;
+     *   winograd_gout       wgrad: that form of gout (used when the weight
+     *                       gradient runs the F(4x4) form, else ignored). */
+    const float *winograd_pre;
+    float *winograd_next;
+    float *winograd_next_gout;
+    const float *winograd_gout;
 } dvsof_conv_desc_t;
 /* dvsof_conv2d_wgrad leaves the columns of the narrow planar members (the
  * 2-channel flow) unwritten: dvsof_flow_fold_grads fills them (below) */
@@ -354,6 +376,9 @@ size_t dvsof_conv2d_scratch_bytes(const dvsof_conv_desc_t *desc);
 /* 0: direct implicit GEMM; 2 | 4: Winograd output tile side used for this
  * problem (kind 0 forward, 1 data gradient, 2 weight gradient); for tools. */
 int dvsof_conv2d_winograd_tile(const dvsof_conv_desc_t *desc, int kind);
+/* 1: the forward (kind 0) / data gradient (kind 1) of this layer accepts
+ * winograd_next [/ winograd_next_gout] (see dvsof_conv_desc_t) */
+int dvsof_conv2d_winograd_chain(const dvsof_conv_desc_t *desc, int kind);
 
 /*
  * Prepared weights.  An upsampled 3x3/pad-1 layer is evaluated as four 2x2

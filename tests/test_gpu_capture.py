@@ -118,7 +118,7 @@ def test_executor_with_the_optimizer_inside_the_backward(dist):
     assert r['dist'] == dist and r['losses_equal'] and r['weights_equal'], r
     x = r['executor']
     # 8 bucket marks + 8 wait marks (one in front of every bucket's update) + the join mark
-    assert x['kernels'] >= 120 and x['marks'] == (17 if dist else 0), x
+    assert x['kernels'] >= 100 and x['marks'] == (17 if dist else 0), x
 
 
 @pytest.mark.parametrize('scenario', ['big:f32', 'big:bf16s', 'big:f32:fused'])

@@ -503,6 +503,64 @@ def test_decoder_dgrad_nine_product_form_epilogue():
                            head_gflow=gf.cuda())], C.ACT_RELU)
 
 
+@pytest.mark.parametrize('B,H,W', [(8, 16, 16), (4, 8, 32), (2, 24, 32)])
+def test_winograd_chain_forms_are_the_consumers_own(B, H, W):
+    """dvsof_conv_desc_t.winograd_next / winograd_next_gout / winograd_pre /
+    winograd_gout (csrc/winograd.hip wino_chain_kernel): a Winograd layer's
+    output transform also writes its consumer's transformed input and gradient
+    form.  Bitwise the same outputs, gradients and weight gradients as the
+    three separate transforms -- forward with residual and Mish (pre-activation
+    copy), data gradient with addend and act'."""
+    from dvs_of_training_framework_amd import conv as C
+    Cc = 256
+    case = dict(B=B, H=H, W=W, src=[(Cc, 'nhwc')], Cout=Cc, stride=1, act='mish')
+    C, xs, w1, b1, d1, act, o = build(case, seed=3)
+    _, _, w2, b2, d2, _, _ = build(case, seed=4)
+    assert C.winograd_tile(d1, 0) == 4 and C.winograd_chain(d1, 0) and C.winograd_chain(d1, 1)
+    dev = 'cuda'
+    u1, u1t = C.prepare(d1, wphys(w1), True)
+    u2, u2t = C.prepare(d2, wphys(w2), True)
+    res = nhwc(torch.randn(B, Cc, H, W))
+
+    def layer2_src(y):      # layer 2 reads layer 1's output
+        d2.src[0].p = y.data_ptr()
+        return y
+    # ---- plain: every call makes its own transforms
+    y1, z1 = C.conv_fwd(d1, u1, b1.cuda(), dev, residual=res, want_z=True, keep_input_transform=True)
+    layer2_src(y1)
+    y2, _ = C.conv_fwd(d2, u2, b2.cuda(), dev, keep_input_transform=True)
+    g2 = nhwc(torch.randn(B, Cc, H, W))
+    add = nhwc(torch.randn(B, Cc, H, W))
+    g1 = torch.empty_like(y1)
+    C.conv_dgrad(d2, u2t, g2, [dict(p=g1, addend=add, actsrc=z1)], act)
+    dw1, db1 = torch.empty(Cc * 9 * Cc, device=dev), torch.empty(Cc, device=dev)
+    C.conv_wgrad(d1, g1, dw1, db1)
+    g0 = torch.empty_like(y1)
+    C.conv_dgrad(d1, u1t, g1, [dict(p=g0)], act)
+    # ---- chained
+    v2 = C.winograd_form(d1, Cc, dev)
+    y1c, z1c = C.conv_fwd(d1, u1, b1.cuda(), dev, residual=res, want_z=True,
+                          keep_input_transform=True, wino_next=v2)
+    layer2_src(y1c)
+    y2c, _ = C.conv_fwd(d2, u2, b2.cuda(), dev, keep_input_transform=True, wino_pre=v2)
+    vg, zg = C.winograd_form(d2, Cc, dev), C.winograd_form(d2, Cc, dev)
+    g1c = torch.empty_like(y1)
+    C.conv_dgrad(d2, u2t, g2, [dict(p=g1c, addend=add, actsrc=z1c)], act,
+                 wino_next=vg, wino_next_gout=zg)
+    dw1c, db1c = torch.empty_like(dw1), torch.empty_like(db1)
+    C.conv_wgrad(d1, g1c, dw1c, db1c, wino_gout=zg if C.winograd_tile(d1, 2) == 4 else None)
+    g0c = torch.empty_like(y1)
+    C.conv_dgrad(d1, u1t, g1c, [dict(p=g0c)], act, wino_pre=vg)
+    for a, b_ in ((y1, y1c), (z1, z1c), (y2, y2c), (g1, g1c), (dw1, dw1c), (db1, db1c), (g0, g0c)):
+        assert torch.equal(a, b_)
+    # a layer that is not a Winograd evaluation refuses the options
+    case3 = dict(B=1, H=8, W=16, src=[(64, 'nhwc')], Cout=64, up=False)
+    C3, xs3, w3, b3, d3, act3, o3 = build(case3, seed=6)
+    assert not C.winograd_chain(d3, 0)
+    with pytest.raises(Exception):
+        C.conv_fwd(d3, wphys(w3), b3.cuda(), dev, wino_next=v2)
+
+
 @pytest.mark.parametrize('Cc,act', [(32, 'relu'), (256, 'relu'), (64, 'mish')])
 def test_flow_head(Cc, act):
     from dvs_of_training_framework_amd import conv as C
