@@ -181,7 +181,16 @@ def audit_exchange(step):
     mark); checked at every recording that has marks, because at one rank the
     collective is an identity and a violation would change nothing there.
     -> {'marks', 'window_kernels', 'checked_pointers', 'violations': [...],
-    'foreign': [...]}; capture.py refuses the recording on a violation."""
+    'foreign': [...]}; capture.py refuses the recording on a violation.
+    Every 8-byte word of a by-value parameter struct is read as a possible
+    pointer (the code object does not describe struct members): the launch
+    sites zero-initialise those structs, so that an unused member slot cannot
+    hold stack residue.  (Round 4: ONE recording of tests/test_gpu_capture.py's
+    accumulation scenario was refused for a word 0x704c00000000 -- not seen
+    again in 5 reruns; three launch sites then still passed `WGradParams P;`
+    with uninitialised unused slots, the likely source: a stale gradient
+    pointer left on the stack by an earlier layer's call.  Unproven: the
+    refusal's full text was lost; capture.py now prints every violation.)"""
     x = step.executor
     assert x is not None
     layouts = kernel_layouts()

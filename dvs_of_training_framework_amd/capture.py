@@ -361,6 +361,8 @@ class CapturedTrainStep:
                 from ._audit import audit_exchange
                 self.exchange_audit = audit_exchange(self)
                 if self.exchange_audit['violations']:
+                    import sys
+                    print('exchange audit:', self.exchange_audit['violations'], file=sys.stderr)
                     raise RuntimeError('a kernel inside the exchange window of a gradient bucket '
                                        f"takes a pointer into it: {self.exchange_audit['violations'][:4]}")
                 self.executor.set_comm(red.comm_handle(), red.exchange_stream(dev))

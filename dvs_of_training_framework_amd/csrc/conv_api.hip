@@ -996,9 +996,9 @@ size_t dvsof_conv2d_wgrad_workspace_bytes(const dvsof_conv_desc_t *d)
         return n + 256;
     }
     if (is_wino_wgrad(d)) return wino_wgrad_workspace_floats(d->B, d->H, d->W, Ctot, d->Cout, d->mfma == 2 ? 2 : 0) * sizeof(float) + 16;
-    WGradParams P;
+    WGradParams P = {};     // (unused member slots are zeros, not stack residue: _audit.audit_exchange reads these words)
     fill_wgrad(d, Ctot, Ho, Wo, P);
-    FlatWG F[3];
+    FlatWG F[3] = {};
     const int nflat = fill_flat(d, Ctot, Ho, Wo, nullptr, F);
     size_t n = wgrad_workspace_floats(P, true) + wgrad_flat_workspace_floats(F, nflat);
     if (is_first_layer(d)) {
@@ -1055,10 +1055,10 @@ int dvsof_conv2d_wgrad(const dvsof_conv_desc_t *d, const float *gout, float *dwe
     if (is_first_layer(d) && !(d->flags & DVSOF_CONV_WGRAD_SKIP_FLAT))
         return first_wgrad_launch(d->src[0].p, d->B, Ctot, d->H, d->W, gout, dweight, dbias, (float *)ws,
                                   ws_bytes / sizeof(float), as_stream(stream));
-    WGradParams P;
+    WGradParams P = {};     // (unused member slots are zeros, not stack residue: _audit.audit_exchange reads these words)
     fill_wgrad(d, Ctot, Ho, Wo, P);
     P.gout = gout;
-    FlatWG F[3];
+    FlatWG F[3] = {};
     // DVSOF_CONV_WGRAD_SKIP_FLAT: the flat members' columns are the caller's
     // (dvsof_flow_fold_grads); the vector members' columns are written as usual
     const int nflat = (d->flags & DVSOF_CONV_WGRAD_SKIP_FLAT) ? 0 : fill_flat(d, Ctot, Ho, Wo, gout, F);
@@ -1254,7 +1254,7 @@ int dvsof_conv2d_tile_id(const dvsof_conv_desc_t *d, int kind)
         return gconv_pick_tile((long long)d->B * d->H * up * d->W * up, n);  // phases included
     }
     if (kind == 2) {
-        WGradParams P;
+        WGradParams P = {};     // (unused member slots are zeros, not stack residue: _audit.audit_exchange reads these words)
         fill_wgrad(d, Ctot, Ho, Wo, P);
         int tile = 0;
         wgrad_splits(P, &tile);

@@ -847,7 +847,7 @@ int pyramid_launch(const float *images, int D, int H, int W, float *const *level
     for (int k = 0; k < K; ++k)
         if (!levels[k] || hs[k] < 1 || ws[k] < 1) return DVSOF_EINVAL;
     static const bool no_fuse = getenv("DVSOF_LOSS_NO_FUSED_PYRAMID") != nullptr;
-    PyrParams Q;
+    PyrParams Q = {};
     if (D > 0 && !no_fuse && pyramid_plan(D, H, W, levels, hs, ws, K, images, Q)) {
         Params dummy = {};
         if (Q.big)

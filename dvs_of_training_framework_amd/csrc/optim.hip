@@ -116,7 +116,7 @@ int dvsof_adamw_step(const uint64_t *ptrs, const int64_t *sizes, const int32_t *
 {
     if (!ptrs || !sizes || !chunks || num_chunks < 0 || step < 1) return DVSOF_EINVAL;
     if (num_chunks == 0) return DVSOF_OK;
-    AdamArgs a;
+    AdamArgs a = {};
     a.lr = lr;
     a.beta1 = beta1;
     a.beta2 = beta2;
@@ -163,7 +163,7 @@ int dvsof_adamw_step_dyn(const uint64_t *ptrs, const int64_t *sizes, const int32
 {
     if (!ptrs || !sizes || !chunks || !dyn || num_chunks < 0) return DVSOF_EINVAL;
     if (num_chunks == 0) return DVSOF_OK;
-    AdamArgs a;
+    AdamArgs a = {};
     a.lr = a.step_size = a.bc2_sqrt = 0.f;   // from dyn
     a.beta1 = beta1;
     a.beta2 = beta2;
@@ -273,7 +273,7 @@ int dvsof_radam_step(const uint64_t *ptrs, const int64_t *sizes, const int32_t *
 {
     if (!ptrs || !sizes || !chunks || num_chunks < 0 || step < 1) return DVSOF_EINVAL;
     if (num_chunks == 0) return DVSOF_OK;
-    RAdamArgs a;
+    RAdamArgs a = {};
     a.lr = lr;
     a.beta1 = beta1;
     a.beta2 = beta2;

@@ -479,7 +479,7 @@ extern "C" {
 
 size_t dvsof_voxelize_workspace_bytes(int64_t n_events, int B, int C, int H, int W)
 {
-    VoxV2 P;
+    VoxV2 P = {};
     // small inputs take the v1 kernel; the encoded entry then expands the
     // columns into the workspace (4 int64 columns)
     if (n_events < 4096 || !v2_plan(n_events, B, C, H, W, P)) return (size_t)n_events * 32 + 64;
@@ -488,7 +488,7 @@ size_t dvsof_voxelize_workspace_bytes(int64_t n_events, int B, int C, int H, int
 
 size_t dvsof_voxelize_control_bytes(int64_t n_events, int B, int C, int H, int W)
 {
-    VoxV2 P;
+    VoxV2 P = {};
     if (n_events < 4096 || !v2_plan(n_events, B, C, H, W, P)) return 0;
     return v2_control_bytes(P);
 }
@@ -498,7 +498,7 @@ int dvsof_voxelize_tiled(const int64_t *x, const int64_t *y, const float *t, con
                          int C, int H, int W, float *out, int32_t *bin0, int64_t *lin0,
                          void *workspace, size_t workspace_bytes, int flags, void *stream)
 {
-    VoxV2 P;
+    VoxV2 P = {};
     if (n < 4096 || !workspace || !v2_plan(n, B, C, H, W, P) || workspace_bytes < v2_bytes(P, n))
         return dvsof_voxelize_fwd(x, y, t, pol, sample, n, t0, t1, B, C, H, W, out, bin0, lin0, stream);
     if (!out || !t0 || !t1 || !x || !y || !t || !pol || !sample) return DVSOF_EINVAL;
@@ -526,7 +526,7 @@ int dvsof_voxelize_encoded(const int16_t *x, const int16_t *y, const float *t,
         return DVSOF_OK;
     }
     if (!x || !y || !t || !polarity || !sample_event_offsets || !workspace) return DVSOF_EINVAL;
-    VoxV2 P;
+    VoxV2 P = {};
     if (n < 4096 || !v2_plan(n, B, C, H, W, P) || workspace_bytes < v2_bytes(P, n)) {
         if (workspace_bytes < (size_t)n * 32) return DVSOF_ENOSPACE;
         int64_t *wx = (int64_t *)workspace, *wy = wx + n, *wp = wy + n, *wsmp = wp + n;
