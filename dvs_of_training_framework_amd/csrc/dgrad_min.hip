@@ -225,6 +225,41 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
     }
 
     // ---- epilogue: [wave][tile][pixel 32][ci 32] rows of 128 bytes, chunks XOR-swizzled by pixel & 7
+    // this wave finishes channel tile t = ks of its pixel tile: which member, where in it
+    const int cit = ci0 + 32 * ks;
+    const int c_first = P.dst[0].C;
+    const int sel = cit >= c_first ? 1 : 0;
+    const GDst &D = P.dst[sel];
+    const int cm = cit - (sel ? c_first : 0);
+    const int ecq = lane & 7;
+    // The epilogue's global operands first: their loads are in flight across the exchange of
+    // the accumulators through LDS (a barrier pins memory operations: issued behind it, every
+    // workgroup of the finest stage -- 2 chunks of K, 8 rounds per CU -- waited for them with
+    // nothing else to do: 158 against 127 us when the head's term joined the epilogue).
+    // A flow head folded into this member's gradient (dvsof_grad_dst_t.head_w): the head's two
+    // weight rows for this lane's 4 channels, the flow's gradient at the lane's pixels.
+    f32x4 hw0 = {0.f, 0.f, 0.f, 0.f}, hw1 = hw0;
+    if (D.head_w) {
+        hw0 = *(const f32x4 *)(D.head_w + cm + 4 * ecq);
+        hw1 = *(const f32x4 *)(D.head_w + D.C + cm + 4 * ecq);
+    }
+    long long eo[4];
+    f32x4 ead[4], ead2[4], eas[4];
+    float eg0[4], eg1[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int px = 8 * it + (lane >> 3);
+        const int yy = oy + 2 * pt + (px >> 4), xx = ox + (px & 15);
+        eo[it] = (long long)b * D.sb + (long long)yy * D.sy + (long long)xx * D.sx + cm + 4 * ecq;
+        if (D.addend) ead[it] = *(const f32x4 *)(D.addend + eo[it]);
+        if (D.addend2) ead2[it] = *(const f32x4 *)(D.addend2 + eo[it]);
+        if (D.actsrc) eas[it] = *(const f32x4 *)(D.actsrc + eo[it]);
+        if (D.head_w) {
+            const long long hwp = (long long)H * W, r = (long long)yy * W + xx;
+            eg0[it] = D.head_g[((long long)b * 2) * hwp + r];
+            eg1[it] = D.head_g[((long long)b * 2 + 1) * hwp + r];
+        }
+    }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -236,41 +271,20 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
         }
     }
     __builtin_amdgcn_s_barrier();
-    // this wave finishes channel tile t = ks of its pixel tile: which member, where in it
-    const int cit = ci0 + 32 * ks;
-    const int c_first = P.dst[0].C;
-    const int sel = cit >= c_first ? 1 : 0;
-    const GDst &D = P.dst[sel];
-    const int cm = cit - (sel ? c_first : 0);
-    const int ecq = lane & 7;
-    // a flow head folded into this member's gradient (dvsof_grad_dst_t.head_w): the head's
-    // two weight rows for this lane's 4 channels
-    f32x4 hw0 = {0.f, 0.f, 0.f, 0.f}, hw1 = hw0;
-    if (D.head_w) {
-        hw0 = *(const f32x4 *)(D.head_w + cm + 4 * ecq);
-        hw1 = *(const f32x4 *)(D.head_w + D.C + cm + 4 * ecq);
-    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int px = 8 * it + (lane >> 3);
         const int xo = px * 128 + ((ecq ^ (px & 7)) << 4);
         f32x4 v = *(const f32x4 *)(smem + (pt * 2 + ks) * 4096 + xo) +
                   *(const f32x4 *)(smem + ((pt + 4) * 2 + ks) * 4096 + xo);
-        const int yy = oy + 2 * pt + (px >> 4), xx = ox + (px & 15);
-        const long long o = (long long)b * D.sb + (long long)yy * D.sy + (long long)xx * D.sx + cm + 4 * ecq;
-        if (D.addend) v += *(const f32x4 *)(D.addend + o);
-        if (D.addend2) v += *(const f32x4 *)(D.addend2 + o);
-        if (D.head_w) {     // + W_h^T g_flow at this pixel (dvsof_flow_head_bwd's data part)
-            const long long hwp = (long long)H * W, r = (long long)yy * W + xx;
-            const float g0 = D.head_g[((long long)b * 2) * hwp + r], g1 = D.head_g[((long long)b * 2 + 1) * hwp + r];
-            v += g0 * hw0 + g1 * hw1;
-        }
+        if (D.addend) v += ead[it];
+        if (D.addend2) v += ead2[it];
+        if (D.head_w) v += eg0[it] * hw0 + eg1[it] * hw1;     // + W_h^T g_flow (dvsof_flow_head_bwd's data part)
         if (D.actsrc) {
-            const f32x4 a = *(const f32x4 *)(D.actsrc + o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_bwd(a[e], P.bwd_act);
+            for (int e = 0; e < 4; ++e) v[e] *= act_bwd(eas[it][e], P.bwd_act);
         }
-        *(f32x4 *)(D.p + o) = v;
+        *(f32x4 *)(D.p + eo[it]) = v;
     }
 #endif
 }

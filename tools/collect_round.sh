@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --output-format csv -d $O/r4_t -o t -- python3 $R/bench
 cd $R
 python3 tools/timeline.py $(find $O/r4_t -name "*kernel_trace.csv") > $O/r4_timeline.txt
 DVSOF_LOOPBACK=2:50 python3 bench.py --steps 20 --warmup 5 --no-roofline --no-other-modes --no-cpu-baseline --no-train-loop > $O/r4_bench_loopback.json 2> $O/r4_bench_loopback.err || { tail -3 $O/r4_bench_loopback.err; exit 1; }
+# (with the per-launch roofline leg: it runs with the reducer detached, bench.py)
+DVSOF_LOOPBACK=2:50 python3 bench.py --steps 10 --warmup 3 --no-other-modes --no-cpu-baseline --no-train-loop > $O/r4_bench_loopback_roofline.json 2> $O/r4_bench_loopback_roofline.err || { tail -3 $O/r4_bench_loopback_roofline.err; exit 1; }
 DVSOF_FORCE_DIST=1 python3 bench.py --steps 20 --warmup 5 --no-roofline --no-other-modes --no-cpu-baseline --no-train-loop > $O/r4_bench_one_rank_rccl.json 2> $O/r4_bench_one_rank_rccl.err || { tail -3 $O/r4_bench_one_rank_rccl.err; exit 1; }
 # keep the summaries, drop the raw traces (the merge back is capped at 64 MiB)
 cp $O/r4_stats/*/s_kernel_stats.csv $O/r4_kernel_stats.csv 2>/dev/null || cp $(find $O/r4_stats -name "*kernel_stats.csv" | head -1) $O/r4_kernel_stats.csv
