@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void min9_dgrad_weights_kernel(const float *__
     }
 }
 
-__global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams P)
+template <int IPW>
+__global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams P, const int total)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -93,52 +94,78 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
     const int FH = 2 * H, FW = 2 * W;               // fine frame (the gradient)
     const int Cout = P.Cin_tot, Ctot = P.N;         // K = output channels of the layer
     const int nbx = W / 16, nby = H / DM_NR;
+    const int nct = Ctot / 64;
+    const int nchunks = Cout / 16;
 
+    // A workgroup walks IPW consecutive ITEMS = (block of pixels, 64-channel tile), channel
+    // tile fastest (XCD-aware: an XCD owns a contiguous range of workgroups; the channel tiles of
+    // a block read the same patch through one L2).  The LDS ring runs on across the items: the
+    // first chunk of item n + 1 is in flight while item n's last chunk is multiplied and its
+    // epilogue runs -- with 2-4 chunks of K per item (the fine stages: 32 | 64 output channels)
+    // a workgroup per item spent a third of its life waiting for its first chunk with nothing
+    // else resident on the CU (151 | 121 us against 107 for the coarsest stage's 16 chunks).
+    // The item loop is unrolled (IPW = 1 | 2): as a loop, or unrolled four times, the compiler
+    // keeps every item's address arithmetic alive across the others (256 registers + 50-111
+    // spilled against 185 | 230).
     unsigned wg = blockIdx.x;
     {
-        const unsigned total = gridDim.x, x = wg & 7u, q = total >> 3, r = total & 7u;
+        const unsigned tot = gridDim.x, x = wg & 7u, q = tot >> 3, r = tot & 7u;
         wg = x * q + min(x, r) + (wg >> 3);
     }
-    const int nct = Ctot / 64;
-    const int ct64 = (int)(wg % (unsigned)nct), blk = (int)(wg / (unsigned)nct);
-    const int ci0 = 64 * ct64;
-    const int bx = blk % nbx, by = (blk / nbx) % nby, b = blk / (nbx * nby);
-    const int oy = DM_NR * by, ox = 16 * bx;
+    const int item0 = (int)wg * IPW, item1 = item0 + IPW;       // (the launch makes IPW divide `total`)
 
-    // ---- DMA roles: piece p = wave + 8 i; lane l lands at piece base + 16 l = row l >> 2, quarter l & 3
     const GSrc &GS = P.src[0];
-    unsigned off[DM_LPW];
-#pragma unroll
-    for (int i = 0; i < DM_LPW; ++i) {
-        const int p = wave + 8 * i;
-        off[i] = DM_OOB;
-        if (p < DM_AP) {
-            const int m = p / 9, pp = p - 9 * m;
-            const int j = 16 * pp + (lane >> 2);        // row within array m: (component, ci >> 2)
-            const int c = j >> 4, r = 4 * (j & 15) + m;
-            off[i] = (unsigned)((((size_t)c * Ctot + ci0 + r) * Cout + 4 * (lane & 3)) * 4);
-        } else if (p < DM_NPIECE) {
-            const int pb = p - DM_AP;
-            const int arr = pb / DM_BPA, pp = pb - DM_BPA * arr;
-            const int pr = 4 * (16 * pp + (lane >> 2)) + (arr & 3);     // column pair
-            if (pr < DM_NPAIR) {
-                const int n = 2 * pr + (arr >> 2);      // fine slot: row n / 34, column n % 34
-                const int fr = n / 34, fc = n - 34 * fr;
-                // (the resource's base is shifted by (-1, -1): offsets stay non-negative)
-                if (((unsigned)(2 * oy + fr - 1) < (unsigned)FH) & ((unsigned)(2 * ox + fc - 1) < (unsigned)FW))
-                    off[i] = (unsigned)((fr * GS.sy + fc * GS.sx + 4 * (lane & 3)) * 4);
-            }
-        }
-    }
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void *)P.W, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(GS.p - ((long long)GS.sy + GS.sx)), 0, 0x7fffffff, 0x00020000);
-    const int gbase = __builtin_amdgcn_readfirstlane(
-        (int)(((long long)b * GS.sb + (long long)(2 * oy) * GS.sy + (long long)(2 * ox) * GS.sx) * 4));
-    const int nchunks = Cout / 16;
+
+    // ---- DMA roles: piece p = wave + 8 i; lane l lands at piece base + 16 l = row l >> 2, quarter l & 3
+    // weight pieces: offsets relative to the item's channel tile (wbase); patch pieces: relative to
+    // the item's block (gbase), with the frame test of that block
+    unsigned off[DM_LPW];
+    int ci0 = 0, b = 0, oy = 0, ox = 0, wbase = 0, gbase = 0;      // of the item being ISSUED
+    auto setup = [&](int item) {
+        const int ct64 = item % nct, blk = item / nct;
+        ci0 = 64 * ct64;
+        const int bx = blk % nbx, by = (blk / nbx) % nby;
+        b = blk / (nbx * nby);
+        oy = DM_NR * by;
+        ox = 16 * bx;
+        wbase = __builtin_amdgcn_readfirstlane((int)((size_t)ci0 * Cout * 4));
+        gbase = __builtin_amdgcn_readfirstlane(
+            (int)(((long long)b * GS.sb + (long long)(2 * oy) * GS.sy + (long long)(2 * ox) * GS.sx) * 4));
+#pragma unroll
+        for (int i = 0; i < DM_LPW; ++i) {
+            const int p = wave + 8 * i;
+            if (p < DM_AP) {
+                const int m = p / 9, pp = p - 9 * m;
+                const int j = 16 * pp + (lane >> 2);        // row within array m: (component, ci >> 2)
+                const int c = j >> 4, r = 4 * (j & 15) + m;
+                off[i] = (unsigned)((((size_t)c * Ctot + r) * Cout + 4 * (lane & 3)) * 4);
+            } else if (p < DM_NPIECE) {
+                off[i] = DM_OOB;
+                const int pb = p - DM_AP;
+                const int arr = pb / DM_BPA, pp = pb - DM_BPA * arr;
+                const int pr = 4 * (16 * pp + (lane >> 2)) + (arr & 3);     // column pair
+                if (pr < DM_NPAIR) {
+                    const int n = 2 * pr + (arr >> 2);      // fine slot: row n / 34, column n % 34
+                    const int fr = n / 34, fc = n - 34 * fr;
+                    // (the resource's base is shifted by (-1, -1): offsets stay non-negative)
+                    if (((unsigned)(2 * oy + fr - 1) < (unsigned)FH) & ((unsigned)(2 * ox + fc - 1) < (unsigned)FW))
+                        off[i] = (unsigned)((fr * GS.sy + fc * GS.sx + 4 * (lane & 3)) * 4);
+                }
+            } else {
+                off[i] = DM_OOB;
+            }
+        }
+    };
 
     auto issue = [&](int stage_idx, int ch) {
         unsigned char *st = smem + stage_idx * DM_STAGE;
+        // (scalar offsets pinned to SGPRs here: as loop-carried values the compiler takes them
+        // for divergent and wraps every LDS-DMA in a waterfall loop)
+        const int so_w = __builtin_amdgcn_readfirstlane(wbase + ch * 64);
+        const int so_g = __builtin_amdgcn_readfirstlane(gbase + ch * 64);
 #pragma unroll
         for (int i = 0; i < DM_LPW; ++i) {
             const int p = wave + 8 * i;
@@ -146,13 +173,13 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
                 const int m = p / 9, pp = p - 9 * m;
                 __attribute__((address_space(3))) void *dst =
                     (__attribute__((address_space(3))) void *)(st + m * DM_AARR + pp * 1024);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, off[i], ch * 64, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, dst, 16, off[i], so_w, 0, 0);
             } else if (p < DM_NPIECE) {
                 const int pb = p - DM_AP;
                 const int arr = pb / DM_BPA, pp = pb - DM_BPA * arr;
                 __attribute__((address_space(3))) void *dst =
                     (__attribute__((address_space(3))) void *)(st + DM_BOFF + arr * DM_BARR + pp * 1024);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, off[i], gbase + ch * 64, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, dst, 16, off[i], so_g, 0, 0);
             }
         }
     };
@@ -175,10 +202,6 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
     }
 
     f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     auto compute = [&](int u_) {
         const unsigned char *st = smem + u_ * DM_STAGE;
@@ -216,75 +239,99 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
         }
     };
 
+    if (item0 >= item1) return;
+    // (more than one item per workgroup only with an EVEN number of chunks: every item then
+    // starts in stage 0 and the stage of a chunk is its parity -- a compile-time constant of the
+    // twice-unrolled chunk loop, i.e. immediate offsets in every fragment read)
+    setup(item0);
     issue(0, 0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ch + 1 < nchunks) issue((ch + 1) & 1, ch + 1);
-        compute(ch & 1);
-    }
+#pragma unroll
+    for (int item = item0; item < item1; ++item) {
+        const int e_ci0 = ci0, e_b = b, e_oy = oy, e_ox = ox;      // this item's (setup moves on below)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ch + 1 < nchunks) issue((ch + 1) & 1, ch + 1);
+            else if (item + 1 < item1) {    // the next item's first chunk
+                setup(item + 1);
+                issue((ch + 1) & 1, 0);
+            }
+            compute(ch & 1);
+        }
 
-    // ---- epilogue: [wave][tile][pixel 32][ci 32] rows of 128 bytes, chunks XOR-swizzled by pixel & 7
-    // this wave finishes channel tile t = ks of its pixel tile: which member, where in it
-    const int cit = ci0 + 32 * ks;
-    const int c_first = P.dst[0].C;
-    const int sel = cit >= c_first ? 1 : 0;
-    const GDst &D = P.dst[sel];
-    const int cm = cit - (sel ? c_first : 0);
-    const int ecq = lane & 7;
-    // The epilogue's global operands first: their loads are in flight across the exchange of
-    // the accumulators through LDS (a barrier pins memory operations: issued behind it, every
-    // workgroup of the finest stage -- 2 chunks of K, 8 rounds per CU -- waited for them with
-    // nothing else to do: 158 against 127 us when the head's term joined the epilogue).
-    // A flow head folded into this member's gradient (dvsof_grad_dst_t.head_w): the head's two
-    // weight rows for this lane's 4 channels, the flow's gradient at the lane's pixels.
-    f32x4 hw0 = {0.f, 0.f, 0.f, 0.f}, hw1 = hw0;
-    if (D.head_w) {
-        hw0 = *(const f32x4 *)(D.head_w + cm + 4 * ecq);
-        hw1 = *(const f32x4 *)(D.head_w + D.C + cm + 4 * ecq);
-    }
-    long long eo[4];
-    f32x4 ead[4], ead2[4], eas[4];
-    float eg0[4], eg1[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int px = 8 * it + (lane >> 3);
-        const int yy = oy + 2 * pt + (px >> 4), xx = ox + (px & 15);
-        eo[it] = (long long)b * D.sb + (long long)yy * D.sy + (long long)xx * D.sx + cm + 4 * ecq;
-        if (D.addend) ead[it] = *(const f32x4 *)(D.addend + eo[it]);
-        if (D.addend2) ead2[it] = *(const f32x4 *)(D.addend2 + eo[it]);
-        if (D.actsrc) eas[it] = *(const f32x4 *)(D.actsrc + eo[it]);
+        // ---- epilogue: [wave][tile][pixel 32][ci 32] rows of 128 bytes, chunks XOR-swizzled by pixel & 7,
+        // in the stage that was multiplied last (the other one is receiving the next item's chunk)
+        unsigned char *xch = smem + ((nchunks - 1) & 1) * DM_STAGE;
+        // this wave finishes channel tile t = ks of its pixel tile: which member, where in it
+        const int cit = e_ci0 + 32 * ks;
+        const int c_first = P.dst[0].C;
+        const int sel = cit >= c_first ? 1 : 0;
+        const GDst &D = P.dst[sel];
+        const int cm = cit - (sel ? c_first : 0);
+        // (the epilogue's lane-derived addresses are made from a laundered copy of the lane id:
+        // as loop invariants of the item loop they would be hoisted above it and stay in registers
+        // through the K loop -- 256 registers + 50 spilled against 188)
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int ecq = le & 7, elrow = le & 31, elh = le >> 5;
+        // The epilogue's global operands first: their loads are in flight across the exchange of
+        // the accumulators through LDS (a barrier pins memory operations: issued behind it, every
+        // workgroup of the finest stage waited for them with nothing else to do: 158 against 127
+        // us when the head's term joined the epilogue).
+        // A flow head folded into this member's gradient (dvsof_grad_dst_t.head_w): the head's two
+        // weight rows for this lane's 4 channels, the flow's gradient at the lane's pixels.
+        f32x4 hw0 = {0.f, 0.f, 0.f, 0.f}, hw1 = hw0;
         if (D.head_w) {
-            const long long hwp = (long long)H * W, r = (long long)yy * W + xx;
-            eg0[it] = D.head_g[((long long)b * 2) * hwp + r];
-            eg1[it] = D.head_g[((long long)b * 2 + 1) * hwp + r];
+            hw0 = *(const f32x4 *)(D.head_w + cm + 4 * ecq);
+            hw1 = *(const f32x4 *)(D.head_w + D.C + cm + 4 * ecq);
         }
-    }
-    __builtin_amdgcn_s_barrier();
+        long long eo[4];
+        f32x4 ead[4], ead2[4], eas[4];
+        float eg0[4], eg1[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        unsigned char *xt_ = smem + (wave * 2 + t) * 4096;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-            *(f32x4 *)(xt_ + lrow * 128 + (((2 * g + lh) ^ (lrow & 7)) << 4)) = v;
+        for (int it = 0; it < 4; ++it) {
+            const int px = 8 * it + (le >> 3);
+            const int yy = e_oy + 2 * pt + (px >> 4), xx = e_ox + (px & 15);
+            eo[it] = (long long)e_b * D.sb + (long long)yy * D.sy + (long long)xx * D.sx + cm + 4 * ecq;
+            if (D.addend) ead[it] = *(const f32x4 *)(D.addend + eo[it]);
+            if (D.addend2) ead2[it] = *(const f32x4 *)(D.addend2 + eo[it]);
+            if (D.actsrc) eas[it] = *(const f32x4 *)(D.actsrc + eo[it]);
+            if (D.head_w) {
+                const long long hwp = (long long)H * W, r = (long long)yy * W + xx;
+                eg0[it] = D.head_g[((long long)e_b * 2) * hwp + r];
+                eg1[it] = D.head_g[((long long)e_b * 2 + 1) * hwp + r];
+            }
         }
-    }
-    __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();       // every wave is done with the last chunk's stage
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int px = 8 * it + (lane >> 3);
-        const int xo = px * 128 + ((ecq ^ (px & 7)) << 4);
-        f32x4 v = *(const f32x4 *)(smem + (pt * 2 + ks) * 4096 + xo) +
-                  *(const f32x4 *)(smem + ((pt + 4) * 2 + ks) * 4096 + xo);
-        if (D.addend) v += ead[it];
-        if (D.addend2) v += ead2[it];
-        if (D.head_w) v += eg0[it] * hw0 + eg1[it] * hw1;     // + W_h^T g_flow (dvsof_flow_head_bwd's data part)
-        if (D.actsrc) {
+        for (int t = 0; t < 2; ++t) {
+            unsigned char *xt_ = xch + (wave * 2 + t) * 4096;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_bwd(eas[it][e], P.bwd_act);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                *(f32x4 *)(xt_ + elrow * 128 + (((2 * g + elh) ^ (elrow & 7)) << 4)) = v;
+            }
         }
-        *(f32x4 *)(D.p + eo[it]) = v;
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = 8 * it + (le >> 3);
+            const int xo = px * 128 + ((ecq ^ (px & 7)) << 4);
+            f32x4 v = *(const f32x4 *)(xch + (pt * 2 + ks) * 4096 + xo) +
+                      *(const f32x4 *)(xch + ((pt + 4) * 2 + ks) * 4096 + xo);
+            if (D.addend) v += ead[it];
+            if (D.addend2) v += ead2[it];
+            if (D.head_w) v += eg0[it] * hw0 + eg1[it] * hw1;     // + W_h^T g_flow (dvsof_flow_head_bwd's data part)
+            if (D.actsrc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_bwd(eas[it][e], P.bwd_act);
+            }
+            *(f32x4 *)(D.p + eo[it]) = v;
+        }
     }
 #endif
 }
@@ -323,12 +370,26 @@ int dgrad_min_launch(const GConvParams &P, hipStream_t st)
     }
     static bool attr_set = false;
     if (!attr_set) {
-        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)dgrad_min_f32_kernel,
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)dgrad_min_f32_kernel<1>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS));
+        DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)dgrad_min_f32_kernel<2>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS));
         attr_set = true;
     }
-    const long long grid = (long long)P.B * (P.Ho / DM_NR) * (P.Wo / 16) * (P.N / 64);
-    hipLaunchKernelGGL(dgrad_min_f32_kernel, dim3((unsigned)grid), dim3(DM_NT), DM_LDS, st, P);
+    // items (pixel block, 64-channel tile) per workgroup.  Two (DVSOF_DGRAD_MIN_IPW=2; needs an even
+    // chunk count: stage = chunk parity) hide the second item's first-chunk latency: alone on the
+    // GPU the finest stage 151 -> 142 us, the others unchanged or worse (230 registers: 121 / 114 /
+    // 108 against 121 / 110 / 107) -- and inside the step, beside the weight-gradient lane, a loss:
+    // 2.538-2.547 against 2.501-2.513 ms.  Default: one.
+    const long long total = (long long)P.B * (P.Ho / DM_NR) * (P.Wo / 16) * (P.N / 64);
+    static const int ipw_env = getenv("DVSOF_DGRAD_MIN_IPW") ? atoi(getenv("DVSOF_DGRAD_MIN_IPW")) : 0;
+    const int nchunks = P.Cin_tot / 16;
+    int ipw = ipw_env == 2 ? 2 : 1;
+    if ((nchunks & 1) || (total & 1)) ipw = 1;
+    if (ipw == 2)
+        hipLaunchKernelGGL(dgrad_min_f32_kernel<2>, dim3((unsigned)(total / 2)), dim3(DM_NT), DM_LDS, st, P, (int)total);
+    else
+        hipLaunchKernelGGL(dgrad_min_f32_kernel<1>, dim3((unsigned)total), dim3(DM_NT), DM_LDS, st, P, (int)total);
     DVSOF_LAUNCH_CHECK();
     return DVSOF_OK;
 }
