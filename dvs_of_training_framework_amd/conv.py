@@ -35,7 +35,7 @@ class GradDst(ctypes.Structure):
     """dvsof_grad_dst_t"""
     _fields_ = [('p', _vp), ('addend', _vp), ('addend2', _vp),
                 ('actsrc', _vp), ('p16', _vp), ('head_w', _vp),
-                ('head_gflow', _vp)]
+                ('head_gflow', _vp), ('head_x', _vp), ('head_part', _vp)]
 
 
 _P = ctypes.POINTER
@@ -45,6 +45,8 @@ _lib.register('dvsof_conv2d_dgrad', _i, [_P(ConvDesc), _vp, _vp, _P(GradDst),
                                          _i, _vp])
 _lib.register('dvsof_conv2d_wgrad_workspace_bytes', _sz, [_P(ConvDesc)])
 _lib.register('dvsof_conv2d_dgrad_fuses_head', _i, [_P(ConvDesc)])
+_lib.register('dvsof_conv2d_dgrad_head_rows', _i, [_P(ConvDesc)])
+_lib.register('dvsof_flow_head_reduce', _i, [_vp, _i, _i, _vp, _vp, _vp])
 _lib.register('dvsof_conv2d_wgrad', _i, [_P(ConvDesc), _vp, _vp, _vp, _vp,
                                          _sz, _vp])
 _lib.register('dvsof_weight_flip_transpose', _i, [_vp, _vp, _i, _i, _i, _vp])
@@ -307,6 +309,8 @@ def conv_dgrad(desc, weight_t, gout, dsts, bwd_act=ACT_NONE, weight16=None,
         arr[i].p16 = _lib.ptr(d.get('p16'))
         arr[i].head_w = _lib.ptr(d.get('head_w'))
         arr[i].head_gflow = _lib.ptr(d.get('head_gflow'))
+        arr[i].head_x = _lib.ptr(d.get('head_x'))
+        arr[i].head_part = _lib.ptr(d.get('head_part'))
     desc.w16 = _lib.ptr(weight16)
     desc.gout16 = _lib.ptr(gout16)
     ws = _scratch(desc, gout.device)     # noqa: F841
@@ -401,6 +405,22 @@ def dgrad_fuses_head(desc):
     """Does this layer's data gradient accept dsts[i]['head_w'] / ['head_gflow']
     (the flow head on a source folded into the epilogue)?"""
     return bool(_lib.lib().dvsof_conv2d_dgrad_fuses_head(ctypes.byref(desc)))
+
+
+def dgrad_head_part(desc, C, device):
+    """Partial-sum buffer for dsts[0]['head_part'] (None: not available)."""
+    rows = _lib.lib().dvsof_conv2d_dgrad_head_rows(ctypes.byref(desc))
+    if rows <= 0:
+        return None
+    return torch.empty(rows, 2 * C + 2, dtype=torch.float32, device=device)
+
+
+def head_reduce(part, C, dw, dbias):
+    """dw, dbias of a flow head from the partials a data gradient left
+    (dsts[0]['head_part']; dvsof_flow_head_reduce)."""
+    _lib.check(_lib.lib().dvsof_flow_head_reduce(
+        part.data_ptr(), part.shape[0], C, dw.data_ptr(), _lib.ptr(dbias),
+        _lib.stream()), 'dvsof_flow_head_reduce')
 
 
 def head_bwd(x, w, gflow, gx_in, actsrc, act, gx, dw, dbias, B, H, W, C,

@@ -831,6 +831,21 @@ int dvsof_conv2d_dgrad_fuses_head(const dvsof_conv_desc_t *d)
     return d && desc_ok(d, Ctot, Ho, Wo) && is_min9_dgrad(d) ? 1 : 0;
 }
 
+int dvsof_conv2d_dgrad_head_rows(const dvsof_conv_desc_t *d)
+{
+    if (!dvsof_conv2d_dgrad_fuses_head(d)) return 0;
+    return d->B * (d->H / 8) * (d->W / 16);     // dgrad_min.hip's pixel blocks
+}
+
+int dvsof_flow_head_reduce(const float *part, int rows, int C, float *dw, float *dbias, void *stream)
+{
+    if (!part || !dw || rows < 1 || C < 1) return DVSOF_EINVAL;
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((2 * C + 2 + 3) / 4), dim3(256), 0, as_stream(stream), part,
+                       rows, C, dw, dbias);
+    DVSOF_LAUNCH_CHECK();
+    return DVSOF_OK;
+}
+
 int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const float *gout,
                        const dvsof_grad_dst_t *dst, int bwd_act, void *stream)
 {
@@ -845,8 +860,10 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         const GSrc g = make_src(nullptr, d->src[i].C, d->src[i].layout, d->H, d->W);
         P.dst[i] = {dst[i].p, dst[i].addend, dst[i].addend2, dst[i].actsrc, g.sb, g.sy, g.sx, g.sc, g.C, 0, 0,
                     (d->mfma == 3 && d->src[i].layout == DVSOF_NHWC) ? (unsigned short *)dst[i].p16 : nullptr,
-                    dst[i].head_w, dst[i].head_gflow};
+                    dst[i].head_w, dst[i].head_gflow, dst[i].head_x, dst[i].head_part};
         if ((dst[i].head_w != nullptr) != (dst[i].head_gflow != nullptr)) return DVSOF_EINVAL;
+        if ((dst[i].head_x != nullptr) != (dst[i].head_part != nullptr)) return DVSOF_EINVAL;
+        if (dst[i].head_part && (!dst[i].head_w || i != 0)) return DVSOF_EINVAL;
         if (dst[i].head_w && !is_min9_dgrad(d)) return DVSOF_EINVAL;   // only dgrad_min.hip folds a head
     }
     P.W = weight_t;

@@ -42,6 +42,8 @@ struct GDst {
     unsigned short *p16;  // optional bf16 twin of p, written with the same offsets
     const float *head_w;  // optional (dgrad_min.hip only): [2][C] weights of a flow head on this member
     const float *head_g;  // ... and the flow's gradient, planar [B][2][H][W]
+    const float *head_x;  // ... optionally the head's input and the per-block partials of its weight / bias
+    float *head_part;     //     gradient, [blocks][2 C + 2]
 };
 
 struct GConvParams {

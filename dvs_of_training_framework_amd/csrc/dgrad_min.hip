@@ -123,9 +123,10 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
     // weight pieces: offsets relative to the item's channel tile (wbase); patch pieces: relative to
     // the item's block (gbase), with the frame test of that block
     unsigned off[DM_LPW];
-    int ci0 = 0, b = 0, oy = 0, ox = 0, wbase = 0, gbase = 0;      // of the item being ISSUED
+    int ci0 = 0, b = 0, oy = 0, ox = 0, wbase = 0, gbase = 0, blk_ = 0;      // of the item being ISSUED
     auto setup = [&](int item) {
         const int ct64 = item % nct, blk = item / nct;
+        blk_ = blk;
         ci0 = 64 * ct64;
         const int bx = blk % nbx, by = (blk / nbx) % nby;
         b = blk / (nbx * nby);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
     issue(0, 0);
 #pragma unroll
     for (int item = item0; item < item1; ++item) {
-        const int e_ci0 = ci0, e_b = b, e_oy = oy, e_ox = ox;      // this item's (setup moves on below)
+        const int e_ci0 = ci0, e_b = b, e_oy = oy, e_ox = ox, e_blk = blk_;      // this item's (setup moves on below)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -290,8 +291,9 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
             hw1 = *(const f32x4 *)(D.head_w + D.C + cm + 4 * ecq);
         }
         long long eo[4];
-        f32x4 ead[4], ead2[4], eas[4];
+        f32x4 ead[4], ead2[4], eas[4], ehx[4];
         float eg0[4], eg1[4];
+        const bool hx_own = D.head_part && D.head_x != D.actsrc;   // (ReLU: the head's input IS actsrc)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int px = 8 * it + (le >> 3);
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
             if (D.addend) ead[it] = *(const f32x4 *)(D.addend + eo[it]);
             if (D.addend2) ead2[it] = *(const f32x4 *)(D.addend2 + eo[it]);
             if (D.actsrc) eas[it] = *(const f32x4 *)(D.actsrc + eo[it]);
+            if (hx_own) ehx[it] = *(const f32x4 *)(D.head_x + eo[it]);
             if (D.head_w) {
                 const long long hwp = (long long)H * W, r = (long long)yy * W + xx;
                 eg0[it] = D.head_g[((long long)e_b * 2) * hwp + r];
@@ -317,6 +320,8 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
             }
         }
         __builtin_amdgcn_s_barrier();
+        f32x4 ha0 = {0.f, 0.f, 0.f, 0.f}, ha1 = ha0;
+        float hs0 = 0.f, hs1 = 0.f;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int px = 8 * it + (le >> 3);
@@ -326,11 +331,54 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
             if (D.addend) v += ead[it];
             if (D.addend2) v += ead2[it];
             if (D.head_w) v += eg0[it] * hw0 + eg1[it] * hw1;     // + W_h^T g_flow (dvsof_flow_head_bwd's data part)
+            if (D.head_part) {  // the head's own weight / bias gradient: sum_px g_flow (x) x
+                const f32x4 xv = hx_own ? ehx[it] : eas[it];
+                ha0 += eg0[it] * xv;
+                ha1 += eg1[it] * xv;
+                hs0 += eg0[it];
+                hs1 += eg1[it];
+            }
             if (D.actsrc) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= act_bwd(eas[it][e], P.bwd_act);
             }
             *(f32x4 *)(D.p + eo[it]) = v;
+        }
+        if (D.head_part) {      // (member 0 only, both K halves of the item: uniform over the workgroup)
+            // lanes of equal `ecq` hold the same 4 channels at 8 different pixels each
+#pragma unroll
+            for (int o_ = 8; o_ < 64; o_ <<= 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ha0[e] += __shfl_xor(ha0[e], o_, 64);
+                    ha1[e] += __shfl_xor(ha1[e], o_, 64);
+                }
+                hs0 += __shfl_xor(hs0, o_, 64);
+                hs1 += __shfl_xor(hs1, o_, 64);
+            }
+            // [wave][2][32] + [wave][2] behind the exchange tiles of this stage (64 KiB of its 77)
+            float *red = (float *)(xch + 65536);
+            if (le < 8) {
+                *(f32x4 *)(red + (wave * 2 + 0) * 32 + 4 * ecq) = ha0;
+                *(f32x4 *)(red + (wave * 2 + 1) * 32 + 4 * ecq) = ha1;
+                if (le == 0) {
+                    red[512 + wave * 2] = hs0;
+                    red[512 + wave * 2 + 1] = hs1;
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            const int Cm = D.C;
+            float *prow = D.head_part + (size_t)e_blk * (2 * Cm + 2);
+            if (tid < 128) {    // (K half, flow channel, channel): the four pixel tiles in order
+                const int ks_ = tid >> 6, k_ = (tid >> 5) & 1, c_ = tid & 31;
+                float t_ = 0.f;
+#pragma unroll
+                for (int p_ = 0; p_ < 4; ++p_) t_ += red[((p_ + 4 * ks_) * 2 + k_) * 32 + c_];
+                prow[k_ * Cm + e_ci0 + 32 * ks_ + c_] = t_;
+            } else if (tid < 130 && e_ci0 == 0) {
+                const int k_ = tid - 128;
+                prow[2 * Cm + k_] = (red[512 + 0 + k_] + red[512 + 2 + k_]) + (red[512 + 4 + k_] + red[512 + 6 + k_]);
+            }
         }
     }
 #endif

@@ -411,7 +411,13 @@ class _PredictorFn(torch.autograd.Function):
         g_skip = [None] * 4  # gradient into e[k] from the decoder
         g_r = g_r16 = None
         head_in_dgrad = False
+        head_part = None
         fuse_heads = os.environ.get('DVSOF_NO_HEAD_FUSE', '0') == '0'
+        # (the head's weight gradient from per-block partials of the same epilogue instead of
+        # its own pass over the tensor on the other stream, dvsof_grad_dst_t.head_part: measured
+        # 2.58 against 2.53 ms wherever the encoder's weight gradients go -- the shuffles, the
+        # extra barrier and the partial stores sit on the data-gradient chain; DVSOF_HEAD_PARTS=1)
+        head_parts = os.environ.get('DVSOF_HEAD_PARTS', '0') == '1'
         for i in (3, 2, 1, 0):
             lay = dec_l[i]
             d = lay['desc']
@@ -425,9 +431,14 @@ class _PredictorFn(torch.autograd.Function):
                 # head's own weight / bias gradient is left, off the critical chain
                 gz, gz16 = g_x, None
 
-                def head_w(y=y, wf=params[pfw], g=g_f, gw=grads[pfw], gb=grads[pfb],
-                           h=h, w=w, c=d.Cout):
-                    C.head_bwd(y, wf, g, None, None, act, None, gw, gb, B, h, w, c)
+                if head_part is not None:
+                    # ... of which that epilogue left per-block partial sums
+                    def head_w(part=head_part, gw=grads[pfw], gb=grads[pfb], c=d.Cout):
+                        C.head_reduce(part, c, gw, gb)
+                else:
+                    def head_w(y=y, wf=params[pfw], g=g_f, gw=grads[pfw], gb=grads[pfb],
+                               h=h, w=w, c=d.Cout):
+                        C.head_bwd(y, wf, g, None, None, act, None, gw, gb, B, h, w, c)
             else:
                 gz, gz16 = new(y), tw(y)
                 C.head_bwd(y, params[pfw], g_f, g_x, asrc(lay), act, gz,
@@ -458,6 +469,11 @@ class _PredictorFn(torch.autograd.Function):
                     head_in_dgrad = True
                     dsts[0].update(head_w=wf_prev, head_gflow=g_fprev,
                                    actsrc=asrc(dec_l[i - 1]))
+                    head_part = C.dgrad_head_part(fold['desc'], dec_l[i - 1]['desc'].Cout, dev) \
+                        if head_parts else None
+                    if head_part is not None:
+                        dsts[0].update(head_x=dec_l[i - 1]['y'], head_part=head_part)
+                        keep.append(head_part)
                 C.conv_dgrad(fold['desc'], fold['w_dg'], gz, dsts, act,
                              weight16=fold['w_dg16'], gout16=gz16)
             else:

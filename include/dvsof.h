@@ -430,6 +430,14 @@ typedef struct {
      * dvsof_flow_head_bwd with gx == NULL).  DVSOF_EINVAL on any other kernel. */
     const float *head_w;
     const float *head_gflow;
+    /* ... and, optionally with them, the head's OWN weight / bias gradient from
+     * the same pass: head_x = the head's input (the tensor p is the gradient of;
+     * may equal actsrc), head_part = [dvsof_conv2d_dgrad_head_rows(desc)][2 C + 2]
+     * floats of per-block partial sums, every element written:
+     * dvsof_flow_head_reduce(head_part, rows, C, dw, dbias) adds them up in a
+     * fixed order (instead of dvsof_flow_head_bwd's second pass over x). */
+    const float *head_x;
+    float *head_part;
 } dvsof_grad_dst_t;
 
 /*
@@ -442,6 +450,10 @@ typedef struct {
 /* 1 when the data gradient of this layer accepts dvsof_grad_dst_t.head_w /
  * head_gflow (shape test alone; see above) */
 int dvsof_conv2d_dgrad_fuses_head(const dvsof_conv_desc_t *desc);
+/* rows of dvsof_grad_dst_t.head_part for this layer (0: not available) */
+int dvsof_conv2d_dgrad_head_rows(const dvsof_conv_desc_t *desc);
+/* dw [2][C], dbias [2] (may be NULL) = column sums of part [rows][2 C + 2] */
+int dvsof_flow_head_reduce(const float *part, int rows, int C, float *dw, float *dbias, void *stream);
 int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *desc, const float *weight_t,
                        const float *gout, const dvsof_grad_dst_t *dst,
                        int bwd_act, void *stream);

@@ -492,6 +492,23 @@ def test_decoder_dgrad_nine_product_form_epilogue():
                2, 16, 32, 128)
     close(dw, torch.einsum('bkyx,bcyx->kc', gf, ysrc))
     close(db, gf.sum((0, 2, 3)))
+    # ... or from per-block partials the same epilogue leaves (head_x / head_part), with the
+    # head's input apart from actsrc (Mish) and the same tensor (ReLU)
+    for hx in (torch.randn(ysrc.shape), ysrc):
+        part = C.dgrad_head_part(desc, 128, 'cuda')
+        assert part is not None and part.shape == (2 * (16 // 8) * (32 // 16), 2 * 128 + 2)
+        part.fill_(float('nan'))        # every element is written
+        hx_d = nhwc(hx)
+        as_d = nhwc(ysrc) if hx is not ysrc else hx_d
+        C.conv_dgrad(desc, wt, nhwc(gz), [dict(p=bufs[0], addend=nhwc(a1), actsrc=as_d,
+                                               head_w=wh.cuda(), head_gflow=gf.cuda(),
+                                               head_x=hx_d, head_part=part),
+                                          dict(p=bufs[1])], C.ACT_RELU)
+        close(from_nhwc(bufs[0]), want_h)
+        dw2, db2 = torch.empty(2, 128, device='cuda'), torch.empty(2, device='cuda')
+        C.head_reduce(part, 128, dw2, db2)
+        close(dw2, torch.einsum('bkyx,bcyx->kc', gf, hx))
+        close(db2, gf.sum((0, 2, 3)))
     # ... and refused where the kernel is another one (here: stride 1, no up-sampling)
     case2 = dict(B=1, H=8, W=16, src=[(64, 'nhwc')], Cout=64, up=False)
     C2, xs2, w2, b2, desc2, act2, o2 = build(case2, seed=6)
