@@ -407,6 +407,12 @@ def dgrad_fuses_head(desc):
     return bool(_lib.lib().dvsof_conv2d_dgrad_fuses_head(ctypes.byref(desc)))
 
 
+def dgrad_head_rows(desc):
+    """> 0: the layer's data gradient is the nine-product kernel (rows of its
+    head_part buffer, dvsof_conv2d_dgrad_head_rows)."""
+    return _lib.lib().dvsof_conv2d_dgrad_head_rows(ctypes.byref(desc))
+
+
 def dgrad_head_part(desc, C, device):
     """Partial-sum buffer for dsts[0]['head_part'] (None: not available)."""
     rows = _lib.lib().dvsof_conv2d_dgrad_head_rows(ctypes.byref(desc))

@@ -825,15 +825,21 @@ int dvsof_conv2d_fwd(const dvsof_conv_desc_t *d, const float *weight, const floa
     return gconv_launch(P, 0, as_stream(stream));
 }
 
+static bool head_fold_ok(const dvsof_conv_desc_t *d)
+{
+    return is_min9_dgrad(d) || (is_subpixel(d) && d->src[0].layout == DVSOF_NHWC);
+}
+
 int dvsof_conv2d_dgrad_fuses_head(const dvsof_conv_desc_t *d)
 {
     int Ctot, Ho, Wo;
-    return d && desc_ok(d, Ctot, Ho, Wo) && is_min9_dgrad(d) ? 1 : 0;
+    return d && desc_ok(d, Ctot, Ho, Wo) && head_fold_ok(d) ? 1 : 0;
 }
 
 int dvsof_conv2d_dgrad_head_rows(const dvsof_conv_desc_t *d)
 {
-    if (!dvsof_conv2d_dgrad_fuses_head(d)) return 0;
+    int Ctot, Ho, Wo;
+    if (!d || !desc_ok(d, Ctot, Ho, Wo) || !is_min9_dgrad(d)) return 0;
     return d->B * (d->H / 8) * (d->W / 16);     // dgrad_min.hip's pixel blocks
 }
 
@@ -864,7 +870,10 @@ int dvsof_conv2d_dgrad(const dvsof_conv_desc_t *d, const float *weight_t, const 
         if ((dst[i].head_w != nullptr) != (dst[i].head_gflow != nullptr)) return DVSOF_EINVAL;
         if ((dst[i].head_x != nullptr) != (dst[i].head_part != nullptr)) return DVSOF_EINVAL;
         if (dst[i].head_part && (!dst[i].head_w || i != 0)) return DVSOF_EINVAL;
-        if (dst[i].head_w && !is_min9_dgrad(d)) return DVSOF_EINVAL;   // only dgrad_min.hip folds a head
+        // a head folds into the nine-product data gradient (dgrad_min.hip) and into the sub-pixel
+        // layers' 4x4 stride-2 form on the general kernels (conv_epilogue), member 0 (NHWC) only
+        if (dst[i].head_w && (i != 0 || !head_fold_ok(d))) return DVSOF_EINVAL;
+        if (dst[i].head_part && !is_min9_dgrad(d)) return DVSOF_EINVAL;
     }
     P.W = weight_t;
     P.W16 = d->mfma == 3 ? (const unsigned short *)d->w16 : nullptr;

@@ -239,6 +239,9 @@ __device__ __forceinline__ void conv_row_offsets(const GConvParams &P, long long
         rowC[r] = valid ? 3 * (Y == 0 ? 1 : Y == P.out_H - 1 ? 2 : 0) + (X == 0 ? 1 : X == P.out_W - 1 ? 2 : 0)
                         : 0;
     }
+    // a flow head folded into member 0's gradient (GDst.head_w; never together with bias_cls):
+    // rowC = the row's offset in plane 0 of the flow gradient [B][2][Ho][Wo]
+    if (P.dst[0].head_w) rowC[r] = valid ? (b * 2 * P.Ho + oy) * P.Wo + ox : -1;
     if (P.quad) {
         oy >>= 1;
         ox >>= 1;
@@ -289,6 +292,13 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
         const long long *ro = rowO + dsel * BM;
         const long long cpart = (long long)(n - off) * sc;
         const float bias = (P.bias && col_ok) ? P.bias[n] : 0.f;
+        // flow head on member 0 (wave-uniform test; the lane's two head weights)
+        const bool has_head = P.dst[0].head_w != nullptr;
+        float hw0 = 0.f, hw1 = 0.f;
+        if (has_head && dsel == 0 && col_ok) {
+            hw0 = P.dst[0].head_w[n];
+            hw1 = P.dst[0].head_w[P.dst[0].C + n];
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int rbase = (wr * TM + tm) * 32 + 4 * (lane >> 5);
@@ -321,6 +331,18 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
                     for (int reg = 0; reg < 16; ++reg) t[reg] = (a2 && o[reg] >= 0) ? a2[o[reg]] : 0.f;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) v[reg] = a2 ? v[reg] + t[reg] : v[reg];
+                }
+                if (has_head) {     // + W_h^T g_flow at the row's pixel (dvsof_flow_head_bwd's data part)
+                    const long long hwp = (long long)P.Ho * P.Wo;
+                    float g0[16], g1[16];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rg = rowC[rbase + (reg & 3) + 8 * (reg >> 2)];
+                        g0[reg] = rg >= 0 ? P.dst[0].head_g[rg] : 0.f;
+                        g1[reg] = rg >= 0 ? P.dst[0].head_g[rg + hwp] : 0.f;
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) v[reg] += g0[reg] * hw0 + g1[reg] * hw1;
                 }
                 if (has_as) {
                     float t[16];

@@ -411,8 +411,9 @@ class _PredictorFn(torch.autograd.Function):
         g_skip = [None] * 4  # gradient into e[k] from the decoder
         g_r = g_r16 = None
         head_in_dgrad = False
-        head_part = None
+        head_part = g_x16 = g_in16 = None
         fuse_heads = os.environ.get('DVSOF_NO_HEAD_FUSE', '0') == '0'
+        fuse_general = os.environ.get('DVSOF_HEAD_FUSE_GENERAL', '0') == '1'
         # (the head's weight gradient from per-block partials of the same epilogue instead of
         # its own pass over the tensor on the other stream, dvsof_grad_dst_t.head_part: measured
         # 2.58 against 2.53 ms wherever the encoder's weight gradients go -- the shuffles, the
@@ -429,7 +430,7 @@ class _PredictorFn(torch.autograd.Function):
                 # the finer stage's data gradient already wrote d/d(pre-activation)
                 # of this stage (head path and act' in its epilogue): only the
                 # head's own weight / bias gradient is left, off the critical chain
-                gz, gz16 = g_x, None
+                gz, gz16 = g_x, g_x16
 
                 if head_part is not None:
                     # ... of which that epilogue left per-block partial sums
@@ -462,13 +463,18 @@ class _PredictorFn(torch.autograd.Function):
                 # path through the flow head, which then sees the loss gradient only
                 g_fprev = gflows[i - 1]
                 wf_prev = params[po_dec + 4 * (i - 1) + 2]
+                # (the general kernels fold a head too, conv_epilogue: bf16s 5 146 against 5 234
+                # samples/s without, bf16 3 941 / 3 912, bf16x3 the same -- their epilogue cannot
+                # start its loads ahead of the K loop's end; DVSOF_HEAD_FUSE_GENERAL=1)
                 if (fuse_heads and C.dgrad_fuses_head(fold['desc'])
+                        and (fuse_general or C.dgrad_head_rows(fold['desc']) > 0)
                         and wf_prev.data_ptr() % 16 == 0):
                     # ... and the head below goes into this data gradient's epilogue
                     # (dvsof_grad_dst_t.head_w): g_in leaves as dec[i-1]'s dz
                     head_in_dgrad = True
+                    g_in16 = tw(g_in)       # (twins mode: the data gradient below reads its bf16 copy)
                     dsts[0].update(head_w=wf_prev, head_gflow=g_fprev,
-                                   actsrc=asrc(dec_l[i - 1]))
+                                   actsrc=asrc(dec_l[i - 1]), p16=g_in16)
                     head_part = C.dgrad_head_part(fold['desc'], dec_l[i - 1]['desc'].Cout, dev) \
                         if head_parts else None
                     if head_part is not None:
@@ -486,6 +492,7 @@ class _PredictorFn(torch.autograd.Function):
             g_skip[3 - i] = g_e
             if i > 0:
                 g_x, g_f = g_in, g_fprev
+                g_x16 = g_in16 if head_in_dgrad else None
             else:
                 g_r = g_in
         # ---- residual blocks (g_r is already d/d pre-activation)

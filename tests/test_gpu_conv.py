@@ -509,6 +509,17 @@ def test_decoder_dgrad_nine_product_form_epilogue():
         C.head_reduce(part, 128, dw2, db2)
         close(dw2, torch.einsum('bkyx,bcyx->kc', gf, hx))
         close(db2, gf.sum((0, 2, 3)))
+    # the same fold in the general kernels' epilogue (here: bf16 operands, where the layer's data
+    # gradient is the 4x4 stride-2 form on gconv2) -- and with a third, planar member beside it
+    desc.mfma = C.MFMA_BF16
+    assert C.dgrad_fuses_head(desc)
+    _, wt16 = C.prepare(desc, wphys(w), True)
+    C.conv_dgrad(desc, wt16, nhwc(gz), [dict(p=bufs[0], addend=nhwc(a1), actsrc=nhwc(ysrc),
+                                             head_w=wh.cuda(), head_gflow=gf.cuda()),
+                                        dict(p=bufs[1])], C.ACT_RELU)
+    close(from_nhwc(bufs[0]), want_h, BF16_RTOL)
+    close(from_nhwc(bufs[1]), xs[1].grad, BF16_RTOL)
+    desc.mfma = C.MFMA_F32
     # ... and refused where the kernel is another one (here: stride 1, no up-sampling)
     case2 = dict(B=1, H=8, W=16, src=[(64, 'nhwc')], Cout=64, up=False)
     C2, xs2, w2, b2, desc2, act2, o2 = build(case2, seed=6)
