@@ -293,7 +293,11 @@ __device__ __forceinline__ void conv_epilogue(const GConvParams &P, f32x16 (&acc
         const long long cpart = (long long)(n - off) * sc;
         const float bias = (P.bias && col_ok) ? P.bias[n] : 0.f;
         // flow head on member 0 (wave-uniform test; the lane's two head weights)
+#ifdef DVSOF_NO_GENERAL_HEAD     // (variant build for A/B runs: tools/variant.sh)
+        const bool has_head = false;
+#else
         const bool has_head = P.dst[0].head_w != nullptr;
+#endif
         float hw0 = 0.f, hw1 = 0.f;
         if (has_head && dsel == 0 && col_ok) {
             hw0 = P.dst[0].head_w[n];
