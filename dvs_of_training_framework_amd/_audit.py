@@ -196,8 +196,27 @@ def audit_exchange(step):
     layouts = kernel_layouts()
     lib = _lib.lib()
     res = {'marks': 0, 'window_kernels': 0, 'checked_pointers': 0, 'violations': [],
-           'foreign': []}
+           'foreign': [], 'update_ranges': 0}
     names = {}
+    # With the optimizer inside the backward (optim.fuse_into_backward) a bucket's UPDATE runs on
+    # a lane of its own behind the collective (csrc/exec.hip, XNode.xlane): the kernels of the
+    # window then also run beside IT, and must not touch the bucket's parameters or optimizer
+    # state either.  bucket pointer -> [(lo, hi)] of those tensors
+    update_ranges = {}
+    pred = getattr(step.model, 'predictor', step.model)
+    if getattr(pred, 'bucket_hook', None) is not None and hasattr(pred, '_buckets'):
+        params = pred.param_list()
+        flats, _ = pred._buckets(params)
+        for b, units in enumerate(pred.BUCKETS):
+            rs = []
+            for u in units:
+                for i in pred.UNIT_PARAMS[u]:
+                    ts = [params[i].data] + [v for v in step.optimizer.state.get(params[i], {}).values()
+                                             if torch.is_tensor(v) and v.is_cuda]
+                    for t in ts:
+                        st_ = t.untyped_storage()
+                        rs.append((st_.data_ptr(), st_.data_ptr() + st_.nbytes()))
+            update_ranges[flats[b].data_ptr()] = rs
 
     def name_of(i):
         if i not in names:
@@ -218,6 +237,8 @@ def audit_exchange(step):
         res['marks'] += 1
         lo = ptr.value or 0
         hi = lo + 4 * n.value
+        extra = update_ranges.get(lo, [])
+        res['update_ranges'] += len(extra)
         for i in list(nodes)[:min(count.value, cap)]:
             name = name_of(i)
             res['window_kernels'] += 1
@@ -235,4 +256,6 @@ def audit_exchange(step):
                     res['checked_pointers'] += 1
                     if lo <= w < hi:
                         res['violations'].append((index.value, i, name[:60], a, hex(w)))
+                    elif any(a_ <= w < b_ for a_, b_ in extra):
+                        res['violations'].append((index.value, i, name[:60], a, hex(w), 'update'))
     return res

@@ -58,6 +58,7 @@ _SIGNATURES = {
     'dvsof_exec_destroy': (_i, [_vp]),
     'dvsof_exec_mark': (_i, [_i, _i, _vp, _sz, _vp]),
     'dvsof_exec_set_comm': (_i, [_vp, _vp, _vp]),
+    'dvsof_exec_set_update_stream': (_i, [_vp, _vp]),
     'dvsof_exec_marks': (_i, [_vp, ctypes.POINTER(_i)]),
     'dvsof_exec_node_arg': (_i, [_vp, _i, _i, _sz, _vp]),
     'dvsof_exec_mark_window': (_i, [_vp, _i, ctypes.POINTER(_vp),

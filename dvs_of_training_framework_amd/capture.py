@@ -127,6 +127,13 @@ class StepExecutor:
         _lib.check(_lib.lib().dvsof_exec_set_comm(
             self._handle, comm, ctypes.c_void_p(exchange_stream.cuda_stream)),
             'dvsof_exec_set_comm')
+        self._info()        # (updates captured behind WAIT marks now have a lane of their own)
+
+    def set_update_stream(self, stream):
+        self._ustream = stream
+        _lib.check(_lib.lib().dvsof_exec_set_update_stream(
+            self._handle, ctypes.c_void_p(stream.cuda_stream)), 'dvsof_exec_set_update_stream')
+        self._info()
 
     def replay(self):
         """One step.  The FIRST call runs it on the current stream alone, timed
@@ -366,6 +373,9 @@ class CapturedTrainStep:
                     raise RuntimeError('a kernel inside the exchange window of a gradient bucket '
                                        f"takes a pointer into it: {self.exchange_audit['violations'][:4]}")
                 self.executor.set_comm(red.comm_handle(), red.exchange_stream(dev))
+                us = red.update_stream(dev)
+                if us is not None:
+                    self.executor.set_update_stream(us)
 
     # ------------------------------------------------------------ the batch
     @staticmethod

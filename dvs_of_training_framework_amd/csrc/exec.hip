@@ -63,6 +63,10 @@ struct XNode {
     hipEvent_t xdone_ev = nullptr;  // BUCKET: the exchange stream's progress behind this collective
     bool xdone_used = false;        // a WAIT mark refers to this BUCKET mark (else xdone_ev is not recorded)
     int wait_for = -1;              // WAIT: position of the BUCKET mark whose collective the lane waits for
+    bool xlane = false;             // runs on the EXCHANGE stream when there is one (see dvsof_exec_create):
+                                    // a kernel captured behind nothing but WAIT marks / such kernels -- a
+                                    // bucket's optimizer update -- and those WAIT marks themselves
+    int lane_plan = 0;              // the plan's lane (xlane nodes: used when there is no exchange stream)
     int lane;
     int id = 0;              // position in capture (topological) order: what plans are written in
     int lane0 = 0;           // lane of the greedy chain split made at creation
@@ -98,6 +102,9 @@ struct Exec {
     void *comm = nullptr;            // dvsof_comm_create handle (not owned)
     hipStream_t xstream = nullptr;   // exchange stream (not owned)
     hipEvent_t xdone = nullptr;      // exchange stream's progress at a JOIN mark
+    hipStream_t ustream = nullptr;   // UPDATE stream: lane of the xlane nodes (own stream: on the exchange
+                                     // stream the updates would sit between the collectives -- under the
+                                     // loopback exchange that stream is the step's longest chain)
 };
 
 // From lanes to waits and events: a node waits for its dependencies in other
@@ -107,6 +114,9 @@ struct Exec {
 int wire(Exec *x)
 {
     const int nn = (int)x->nodes.size();
+    // the exchange stream is one more lane (index max_lanes) for the nodes that belong on it
+    const bool xl = x->comm && x->xstream && x->ustream;
+    for (auto &n : x->nodes) n.lane = (n.xlane && xl) ? x->max_lanes : n.lane_plan;
     int L = 0;
     for (auto &n : x->nodes) L = std::max(L, n.lane + 1);
     x->tail.assign(L, -1);
@@ -304,7 +314,7 @@ void apply(Exec *x, const Plan &p)
         nv.push_back(std::move(x->nodes[by_id[p.order[k]]]));
     }
     for (auto &n : nv) {
-        n.lane = p.lane[n.id];
+        n.lane = n.lane_plan = p.lane[n.id];
         n.deps.clear();
         for (int d : n.deps_id) n.deps.push_back(newpos[d]);
         std::sort(n.deps.begin(), n.deps.end());
@@ -389,12 +399,23 @@ int dvsof_exec_set_comm(void *exec, void *comm, void *exchange_stream)
     x->comm = comm;
     x->xstream = as_stream(exchange_stream);
     if (comm && !x->xdone) DVSOF_HIP_TRY(hipEventCreateWithFlags(&x->xdone, hipEventDisableTiming));
+    // (without dvsof_exec_set_update_stream the updates go on the exchange stream itself, between
+    // the collectives)
+    if (comm && x->xstream && !x->ustream) x->ustream = x->xstream;
     for (auto &n : x->nodes)
         if (comm && n.mark == DVSOF_MARK_BUCKET && !n.mark_ev) {
             DVSOF_HIP_TRY(hipEventCreateWithFlags(&n.mark_ev, hipEventDisableTiming));
             DVSOF_HIP_TRY(hipEventCreateWithFlags(&n.xdone_ev, hipEventDisableTiming));
         }
-    return DVSOF_OK;
+    return wire(x);     // the exchange stream's lane exists from here on
+}
+
+int dvsof_exec_set_update_stream(void *exec, void *update_stream)
+{
+    if (!exec || !update_stream) return DVSOF_EINVAL;
+    Exec *x = (Exec *)exec;
+    x->ustream = as_stream(update_stream);
+    return wire(x);
 }
 
 int dvsof_exec_marks(void *exec, int *n_marks)
@@ -614,6 +635,32 @@ int dvsof_exec_create(void *graph_, void *const *side_streams, int n_side, void 
         std::sort(out.begin(), out.end());
         n.deps = n.deps_id = out;
     }
+    // Nodes of the exchange stream: a kernel whose every dependency is a WAIT mark or such a kernel
+    // (parallel.GradReducer captures a bucket's optimizer update on the exchange stream, behind the
+    // bucket's WAIT mark: the update follows the collective in stream order and no compute lane waits
+    // for either), and the WAIT marks all of whose successors are such kernels.
+    {
+        std::vector<std::vector<int>> succ(nn);
+        for (size_t i = 0; i < nn; ++i)
+            for (int d : x->nodes[i].deps_id) succ[d].push_back((int)i);
+        for (size_t i = 0; i < nn; ++i) {       // capture order is a topological order
+            XNode &n = x->nodes[i];
+            if (n.mark || !n.kernel || n.deps_id.empty()) continue;
+            bool all = true;
+            for (int d : n.deps_id)
+                if (!(x->nodes[d].mark == DVSOF_MARK_WAIT || x->nodes[d].xlane)) all = false;
+            n.xlane = all;
+        }
+        for (size_t i = 0; i < nn; ++i) {
+            XNode &n = x->nodes[i];
+            if (n.mark != DVSOF_MARK_WAIT || succ[i].empty()) continue;
+            bool all = true;
+            for (int s_ : succ[i])
+                if (!x->nodes[s_].xlane) all = false;
+            n.xlane = all;
+        }
+        for (auto &n : x->nodes) n.lane_plan = n.lane;
+    }
     for (int l = 0; l < n_side; ++l) x->side.push_back((hipStream_t)side_streams[l]);
     {
         const int rc = wire(x);
@@ -760,11 +807,11 @@ int dvsof_exec_launch(void *exec, void *stream)
         if (rc_) return rc_;
     }
     const int L = (int)x->tail.size();
-    auto lane_stream = [&](int l) { return l == 0 ? main : x->side[l - 1]; };
+    auto lane_stream = [&](int l) { return l == 0 ? main : l <= (int)x->side.size() ? x->side[l - 1] : x->ustream; };
     if (x->trial_cur >= 0) DVSOF_HIP_TRY(hipEventRecord(x->t0, main));
     if (L > 1) {   // the side lanes start behind whatever precedes the step on `stream`
         DVSOF_HIP_TRY(hipEventRecord(x->fork, main));
-        for (int l = 1; l < L; ++l) DVSOF_HIP_TRY(hipStreamWaitEvent(x->side[l - 1], x->fork, 0));
+        for (int l = 1; l < L; ++l) DVSOF_HIP_TRY(hipStreamWaitEvent(lane_stream(l), x->fork, 0));
     }
     for (auto &n : x->nodes) {
         hipStream_t st = lane_stream(n.lane);
@@ -779,7 +826,7 @@ int dvsof_exec_launch(void *exec, void *stream)
         if (n.ev) DVSOF_HIP_TRY(hipEventRecord(n.ev, st));
     }
     for (int l = 1; l < L; ++l) {   // `stream` continues behind every lane
-        DVSOF_HIP_TRY(hipEventRecord(x->join[l - 1], x->side[l - 1]));
+        DVSOF_HIP_TRY(hipEventRecord(x->join[l - 1], lane_stream(l)));
         DVSOF_HIP_TRY(hipStreamWaitEvent(main, x->join[l - 1], 0));
     }
     if (x->trial_cur >= 0) DVSOF_HIP_TRY(hipEventRecord(x->t1, main));

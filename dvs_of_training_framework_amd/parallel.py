@@ -35,6 +35,7 @@ def _stdout_to_stderr():
 
 
 _EXCHANGE_STREAMS = {}      # device index -> the stream of the collectives
+_UPDATE_STREAMS = {}        # device index -> the stream of the per-bucket optimizer updates
 
 
 def claim_streams(device):
@@ -59,7 +60,8 @@ def claim_streams(device):
         # (one workgroup with ~all of its LDS each) -- small kernels of the other lane were seen
         # waiting 20-70 us for a slot (profiles/round4/timeline.txt)
         _EXCHANGE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1)
-        for s in (torch.cuda.current_stream(dev), side, _EXCHANGE_STREAMS[key]):
+        _UPDATE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        for s in (torch.cuda.current_stream(dev), side, _EXCHANGE_STREAMS[key], _UPDATE_STREAMS[key]):
             if s is not None:
                 with torch.cuda.stream(s):
                     torch.zeros(64, device=dev).add_(1.0)     # a kernel: the queue is bound now
@@ -187,6 +189,16 @@ class GradReducer:
                 return _SIDE_STREAMS[key]
         return self._side_stream(device)
 
+    def update_stream(self, device):
+        """Stream of the update lane (dvsof_exec_set_update_stream), claimed with the others;
+        None: the updates stay on the exchange stream (DVSOF_UPDATE_ON_XSTREAM=1, or the streams
+        were not claimed)."""
+        if os.environ.get('DVSOF_UPDATE_ON_XSTREAM') == '1':
+            return None
+        key = torch.device(device).index
+        key = torch.cuda.current_device() if key is None else key
+        return _UPDATE_STREAMS.get(key)
+
     def _make_comm(self):
         import ctypes
         from . import _lib
@@ -244,15 +256,34 @@ class GradReducer:
             _lib.check(_lib.lib().dvsof_exec_mark(
                 1, self._marked, flat.data_ptr(), flat.numel(), _lib.stream()),
                 'dvsof_exec_mark')
-            if after is not None:
-                # optim.fuse_into_backward: this bucket's update behind a WAIT mark -- the
-                # executor makes the lane wait for THIS bucket's collective there
+            if after is not None and os.environ.get('DVSOF_UPDATE_ON_LANE') == '1':
+                # (before round 4's second half: this bucket's update behind a WAIT mark on the
+                # CURRENT stream -- the executor makes that lane wait for the collective there:
+                # 3.18 against 2.65 ms per step under the loopback exchange, the lane stalls)
                 _lib.check(_lib.lib().dvsof_exec_mark(
                     3, self._marked, flat.data_ptr(), flat.numel(), _lib.stream()),
                     'dvsof_exec_mark')
                 self._marked += 1
                 after()
                 return
+            if after is not None:
+                # optim.fuse_into_backward: this bucket's update is captured ON THE EXCHANGE
+                # STREAM, behind a WAIT mark there (the branch joins the capture again in
+                # wait()).  The executor recognises kernels that follow nothing but WAIT marks
+                # and launches them on the exchange stream behind the collective: the update
+                # overlaps the rest of the backward and no compute lane waits for anything
+                # before the JOIN mark (csrc/exec.hip, XNode.xlane).
+                cur = torch.cuda.current_stream(flat.device)
+                side = self._side_stream(flat.device)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    _lib.check(_lib.lib().dvsof_exec_mark(
+                        3, self._marked, flat.data_ptr(), flat.numel(), _lib.stream()),
+                        'dvsof_exec_mark')
+                    after()
+                self._capture_branch = side
             self._marked += 1
             return
         self.bytes_reduced += flat.numel() * flat.element_size()
@@ -303,6 +334,9 @@ class GradReducer:
     def wait(self):
         if self._marked and torch.cuda.is_current_stream_capturing():
             from . import _lib      # the optimizer kernels come behind the exchange
+            branch, self._capture_branch = getattr(self, '_capture_branch', None), None
+            if branch is not None:      # the updates captured on the exchange stream join here
+                torch.cuda.current_stream().wait_stream(branch)
             _lib.check(_lib.lib().dvsof_exec_mark(2, 0, None, 0, _lib.stream()),
                        'dvsof_exec_mark')
             self._marked = 0

@@ -749,6 +749,14 @@ int dvsof_comm_create_loopback(void **comm, int world_size, int delay_us);
 #define DVSOF_MARK_WAIT 3
 int dvsof_exec_mark(int kind, int index, float *bucket, size_t n, void *stream);
 int dvsof_exec_set_comm(void *exec, void *comm, void *exchange_stream);
+/* Stream of the UPDATE lane: kernels captured behind nothing but WAIT marks (a
+ * bucket's optimizer update, captured on the exchange stream by
+ * parallel.GradReducer) are replayed there, each behind its bucket's
+ * collective, and no compute lane waits before the JOIN mark.  Without this
+ * call they run on the exchange stream itself, between the collectives.  A
+ * stream of its own hardware queue (first used before any communicator
+ * exists: parallel.claim_streams). */
+int dvsof_exec_set_update_stream(void *exec, void *update_stream);
 int dvsof_exec_marks(void *exec, int *n_marks);
 /* The exchange window of the k-th BUCKET mark (capture order): the kernels
  * captured behind the mark that are not behind its WAIT mark (or, without one,
