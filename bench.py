@@ -226,8 +226,11 @@ class Harness:
                 and not os.environ.get('DVSOF_LOOPBACK')
             fo = 'buckets' if getattr(a, 'dtype', 'f32') == 'f32' and alone else 'none'
         if fo != 'none':
+            flush = (5,)
+            if os.environ.get('DVSOF_FLUSH_AT'):    # (experiments: other flush points of 'coarse')
+                flush = tuple(int(v) for v in os.environ['DVSOF_FLUSH_AT'].split(','))
             self.opt.fuse_into_backward(self.model.predictor,
-                                        flush_at=None if fo == 'buckets' else (5,))
+                                        flush_at=None if fo == 'buckets' else flush)
         self.fused_optimizer = fo
         self.sched = torch.optim.lr_scheduler.LambdaLR(
             self.opt, lambda s: 2 ** (-s / 100000))
