@@ -177,6 +177,12 @@ Plan plan_by_time(const Exec *x)
     std::vector<char> taken(nn, 0);
     std::vector<int> lane(nn, 0);
     int left = nn;
+    for (int i = 0; i < nn; ++i)    // the update lane's nodes take no compute lane (wire() places them)
+        if (x->nodes[i].xlane) {
+            taken[i] = 1;
+            lane[i] = x->max_lanes - 1;
+            --left;
+        }
     for (int l = 0; l < x->max_lanes && left > 0; ++l) {
         if (l == x->max_lanes - 1) {
             for (int i = 0; i < nn; ++i)
@@ -280,6 +286,17 @@ Plan plan_by_list(const Exec *x, double hop)
         }
         const int i = ready[pick];
         ready.erase(ready.begin() + (long)pick);
+        if (x->nodes[i].xlane) {    // on the update lane: occupies no compute lane
+            double t = 0.0;
+            for (int d : x->nodes[i].deps) t = std::max(t, fin[d]);
+            lane[i] = L - 1;
+            fin[i] = t + (double)x->nodes[i].us;
+            p.order.push_back(x->nodes[i].id);
+            p.lane[x->nodes[i].id] = L - 1;
+            for (int s_ : succ[i])
+                if (--indeg[s_] == 0) ready.push_back(s_);
+            continue;
+        }
         int best_l = 0;
         double best_t = 0.0;
         for (int l = 0; l < L; ++l) {
