@@ -668,12 +668,12 @@ int dvsof_exec_create(void *graph_, void *const *side_streams, int n_side, void 
                 if (!(x->nodes[d].mark == DVSOF_MARK_WAIT || x->nodes[d].xlane)) all = false;
             n.xlane = all;
         }
-        for (size_t i = 0; i < nn; ++i) {
-            XNode &n = x->nodes[i];
-            if (n.mark != DVSOF_MARK_WAIT || succ[i].empty()) continue;
+        for (size_t k = nn; k-- > 0;) {     // (descending: a WAIT mark's successor may be the next WAIT mark
+            XNode &n = x->nodes[k];         // of the branch -- an update that collects several buckets)
+            if (n.mark != DVSOF_MARK_WAIT || succ[k].empty()) continue;
             bool all = true;
-            for (int s_ : succ[i])
-                if (!x->nodes[s_].xlane) all = false;
+            for (int s_ : succ[k])
+                if (!(x->nodes[s_].xlane || x->nodes[s_].mark == DVSOF_MARK_JOIN)) all = false;
             n.xlane = all;
         }
         for (auto &n : x->nodes) n.lane_plan = n.lane;
