@@ -249,6 +249,10 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
     // waves of a SIMD already cover each other's read -> subtract phases.)
     // ---- epilogue.  Phase tiles (a, b) = sums of four components; [pixel 32][co 32] rows of
     // 128 bytes per (wave, phase), 16-byte chunks XOR-swizzled by pixel & 7
+    // (the bias is loaded ahead of the barriers: behind them its latency is every workgroup's own)
+    const int ecq = lane & 7;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias) bias4 = *(const f32x4 *)(P.bias + co0 + 4 * ecq);
     __builtin_amdgcn_s_barrier();       // every wave is done with the stages
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -263,9 +267,6 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
     }
     __builtin_amdgcn_s_barrier();
     const GDst &D = P.dst[0];
-    const int ecq = lane & 7;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (P.bias) bias4 = *(const f32x4 *)(P.bias + co0 + 4 * ecq);
     // this wave finishes phases f = ks, ks + KS, ... of its pixel tile
 #pragma unroll
     for (int fi = 0; fi < 4 / G::KS; ++fi) {
