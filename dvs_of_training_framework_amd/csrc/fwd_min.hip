@@ -243,6 +243,12 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
         compute(ch & 1);
     }
 
+    // (Measured and not kept: the twelve subtractions pinned to v_pk_add_f32 by inline asm -- the
+    // compiler splits most of them into scalar pairs, 86 v_add_f32 per unrolled chunk -- with the
+    // two wait states a matrix instruction needs behind a vector write of its operand, which a
+    // hand-written instruction hides from the hazard recogniser (without them: wrong sums):
+    // 109 / 101 / 107 / 118 us per stage against 105 / 102 / 109 / 121, 2.518 against 2.526 ms per
+    // step -- the K loop is not bound by its vector instructions.)
     // (Measured and not kept, batch 8: the next group's 18 fragment reads issued ahead of this
     // group's matrix instructions -- register double buffering, with and without
     // sched_group_barrier ordering: 105-136 / 108-164 us per stage against 101-119; the two
