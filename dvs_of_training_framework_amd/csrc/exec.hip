@@ -776,6 +776,14 @@ int dvsof_exec_calibrate(void *exec, void *stream)
     int fixed = -1;
     for (size_t i = 0; want && i < x->cands.size(); ++i)
         if (!strcmp(want, x->cands[i].name)) fixed = (int)i;
+    // Under an exchange every rank takes the SAME plan, the capture's own two-stream split
+    // ("chain": what the trials picked in every 1-rank and loopback run): timed trials would
+    // measure the other ranks' arrival at the collectives as much as this rank's kernels, ranks
+    // could settle on different plans, and the trial steps themselves (host waits for a step's
+    // end) are one more place where ranks wait for each other.  DVSOF_EXEC_PLAN overrides.
+    if (fixed < 0 && !want && x->comm)
+        for (size_t i = 0; i < x->cands.size(); ++i)
+            if (!strcmp("chain", x->cands[i].name)) fixed = (int)i;
     if (fixed >= 0) {
         apply(x, x->cands[fixed]);
         x->cands.clear();
