@@ -205,14 +205,23 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
 
     auto compute = [&](int u) {
         const unsigned char *st = smem + u * G::STAGE;
+#ifdef FM_STAGGER       // experiment: the second wave of every SIMD starts its chunk late (x 64 cycles): 9 ->
+        if (wave >= 4) __builtin_amdgcn_s_sleep(FM_STAGGER);     // 105 / 101 / 106 / 118 against 106 / 103 / 109 / 122 us
+#endif
 #pragma unroll
         for (int gi = 0; gi < 8 / G::KS; ++gi) {
             const int kg = ks + G::KS * gi;             // group of 4 channels (16 bytes of a row)
             f32x2 a[9], x[9];
+#ifndef FM_PROBE
+#define FM_PROBE 0      // timing probes (variant builds, tools/variant.sh; results wrong): 1 no DMA behind the
+#endif                  // second chunk, 2 one weight and one patch fragment read per group instead of 18, 4 no barrier
+                        // per stage, us: 104 102 108 120 | 1: 101 99 106 117 | 2: 83 82 87 97 | 4: 91 92 98 110 |
+                        // 7: 73 75 78 86 (= the matrix pipe's own time): the fragment reads cost 20 %, the chunk
+                        // barrier 12 %, the DMA 3 %
 #pragma unroll
-            for (int c = 0; c < 9; ++c) a[c] = *(const f32x2 *)(st + abase + c * 512 + 16 * kg);
+            for (int c = 0; c < 9; ++c) a[c] = *(const f32x2 *)(st + abase + ((FM_PROBE & 2) ? 0 : c) * 512 + 16 * kg);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) x[c] = *(const f32x2 *)(st + bbase[c] + 16 * kg);
+            for (int c = 0; c < 9; ++c) x[c] = *(const f32x2 *)(st + bbase[(FM_PROBE & 2) ? 0 : c] + 16 * kg);
             // rows, then columns: Xt[p][q]
             f32x2 rw[3][3], xt[9];
 #pragma unroll
@@ -238,8 +247,8 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
     issue(0, 0);
     for (int ch = 0; ch < nchunks; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ch + 1 < nchunks) issue((ch + 1) & 1, ch + 1);
+        if (!(FM_PROBE & 4) || ch == 0) __builtin_amdgcn_s_barrier();
+        if (ch + 1 < nchunks && (!(FM_PROBE & 1) || ch == 0)) issue((ch + 1) & 1, ch + 1);
         compute(ch & 1);
     }
 
