@@ -20,13 +20,14 @@
 // is (pixel tile of 2 rows x 16 pixels, K slice): it holds the nine 32 x 32
 // accumulators M[p][q] of its pixels and takes every KS-th group of 4 channels
 // (KS = 16 / NR slices: with few pixels per workgroup the waves split K; they
-// meet once, in the epilogue).  Per group of 4 channels a wave reads 9 weight
-// and 9 patch fragments (ds_read_b64: two K steps each), makes the nine Xt
-// pairs with 12 packed subtractions and issues 18 matrix instructions.
+// meet once, in the epilogue).  Per group of 8 channels a wave reads 9 weight
+// and 9 patch fragments (ds_read_b128: the lane halves take channels 0-3 / 4-7,
+// four K steps each), makes the nine Xt quads with 12 x 2 packed subtractions
+// and issues 36 matrix instructions.
 // LDS images without swizzles: rows (patch slots / weight rows) are dealt to
-// eight arrays by row mod 8, each array padded by 16 bytes -- the 32 lanes of
-// a fragment read then meet 2 per bank pair, and the chunk index stays an
-// immediate offset.
+// eight arrays by row mod 8, each array padded by 16 bytes -- eight lanes of
+// a fragment read then cover the 32 banks once (16 bytes each, no conflict),
+// and the chunk index stays an immediate offset.
 // Epilogue: nine accumulators -> four phase tiles in registers, K slices and
 // the transposition to pixel-major meet in LDS, 8 lanes store one output
 // pixel's 128 bytes: bias, border-class bias (flow fold), pre-activation copy,
@@ -186,7 +187,12 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
 
     // ---- fragment addresses (relative to a stage)
     // A: row R = 32 c + lrow -> array lrow & 7, row 4 c + (lrow >> 3)
-    const int abase = (lrow & 7) * FM_AARR + (lrow >> 3) * 128 + 8 * lh;
+#ifndef FM_B64
+    constexpr int FRAG = 16;    // bytes of a row a lane reads per group: 4 channels (ds_read_b128), see compute
+#else
+    constexpr int FRAG = 8;     // (-DFM_B64: 2 channels per read, groups of 4 channels -- the form before)
+#endif
+    const int abase = (lrow & 7) * FM_AARR + (lrow >> 3) * 128 + FRAG * lh;
     // B: slot n = (2 pt + (lrow >> 4) + r) 18 + (lrow & 15) + c -> array n & 7, row n >> 3
     int bbase[9];
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int n = (2 * pt + (lrow >> 4) + r) * 18 + (lrow & 15) + c;
-            bbase[3 * r + c] = G::BOFF + (n & 7) * G::BARR + (n >> 3) * 128 + 8 * lh;
+            bbase[3 * r + c] = G::BOFF + (n & 7) * G::BARR + (n >> 3) * 128 + FRAG * lh;
         }
 
     f32x16 acc[9];
@@ -203,21 +209,60 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
+#ifndef FM_PROBE
+#define FM_PROBE 0      // timing probes (variant builds with -DFM_B64, tools/variant.sh; results wrong): 1 no DMA
+#endif                  // behind the second chunk, 2 one weight and one patch fragment read per group instead of 18,
+                        // 4 no barrier.  Per stage, us (8-byte fragment reads): 104 102 108 120 | 1: 101 99 106 117 |
+                        // 2: 83 82 87 97 | 4: 91 92 98 110 | 7: 73 75 78 86 (= the matrix pipe's own time): the
+                        // fragment reads cost 20 %, the chunk barrier 12 %, the DMA 3 %
     auto compute = [&](int u) {
         const unsigned char *st = smem + u * G::STAGE;
 #ifdef FM_STAGGER       // experiment: the second wave of every SIMD starts its chunk late (x 64 cycles): 9 ->
         if (wave >= 4) __builtin_amdgcn_s_sleep(FM_STAGGER);     // 105 / 101 / 106 / 118 against 106 / 103 / 109 / 122 us
 #endif
+#ifndef FM_B64
+        // Groups of EIGHT channels: a lane reads 16 bytes of its row (ds_read_b128: the low half of
+        // the wave channels 0-3 of the group, the high half 4-7 -- any assignment of K to the two
+        // lane halves will do as long as both operands use the same) and feeds FOUR matrix
+        // instructions per component with them.  8 lanes x 16 bytes = one pass over the 32 banks
+        // without a conflict in this layout, where the 8-byte reads met two per bank pair: half
+        // the LDS time and half the read instructions per matrix instruction (the fragment reads
+        // cost 20 % of a stage, FM_PROBE).  The weight fragments are fetched one component ahead.
+#pragma unroll
+        for (int gi = 0; gi < 4 / G::KS; ++gi) {
+            const int kg = ks + G::KS * gi;             // group of 8 channels (32 bytes of a row)
+            f32x4 x[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) x[c] = *(const f32x4 *)(st + bbase[c] + 32 * kg);
+            f32x4 an = *(const f32x4 *)(st + abase + 32 * kg);
+            // rows, then columns: Xt[p][q]
+            f32x4 rw[3][3], xt[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rw[0][c] = x[c] - x[3 + c];
+                rw[1][c] = x[3 + c];
+                rw[2][c] = x[6 + c] - x[3 + c];
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                xt[3 * p] = rw[p][0] - rw[p][1];
+                xt[3 * p + 1] = rw[p][1];
+                xt[3 * p + 2] = rw[p][2] - rw[p][1];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const f32x4 ac = an;
+                if (c + 1 < 9) an = *(const f32x4 *)(st + abase + (c + 1) * 512 + 32 * kg);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j], xt[c][j], acc[c], 0, 0, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int gi = 0; gi < 8 / G::KS; ++gi) {
             const int kg = ks + G::KS * gi;             // group of 4 channels (16 bytes of a row)
             f32x2 a[9], x[9];
-#ifndef FM_PROBE
-#define FM_PROBE 0      // timing probes (variant builds, tools/variant.sh; results wrong): 1 no DMA behind the
-#endif                  // second chunk, 2 one weight and one patch fragment read per group instead of 18, 4 no barrier
-                        // per stage, us: 104 102 108 120 | 1: 101 99 106 117 | 2: 83 82 87 97 | 4: 91 92 98 110 |
-                        // 7: 73 75 78 86 (= the matrix pipe's own time): the fragment reads cost 20 %, the chunk
-                        // barrier 12 %, the DMA 3 %
 #pragma unroll
             for (int c = 0; c < 9; ++c) a[c] = *(const f32x2 *)(st + abase + ((FM_PROBE & 2) ? 0 : c) * 512 + 16 * kg);
 #pragma unroll
@@ -242,6 +287,7 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][1], xt[c][1], acc[c], 0, 0, 0);
             }
         }
+#endif
     };
 
     issue(0, 0);
