@@ -187,7 +187,7 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
 
     // ---- fragment addresses (relative to a stage)
     // A: weight row (component c, ci r = 32 ct + lrow) -> array r & 3, row 16 c + (r >> 2)
-    const int abase = (lrow & 3) * DM_AARR + (lrow >> 2) * 64 + 8 * lh;
+    const int abase = (lrow & 3) * DM_AARR + (lrow >> 2) * 64 + 16 * lh;    // (16-byte fragment reads, see compute)
     // B: window element (u, v) of pixel (li, lj) of this wave's tile: fine slot
     // n = (2 (2 pt + li) + u) 34 + 2 lj + v -> plane v & 1, pair (n >> 1) = (...) 17 + lj + (v >> 1)
     int bb[4][2];
@@ -198,46 +198,51 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int pr = (2 * (2 * pt + li) + u) * DM_PR + lj + h;
-                bb[u][h] = DM_BOFF + (pr & 3) * DM_BARR + (pr >> 2) * 64 + 8 * lh;
+                bb[u][h] = DM_BOFF + (pr & 3) * DM_BARR + (pr >> 2) * 64 + 16 * lh;
             }
     }
 
     f32x16 acc[2];
 
+    // A wave takes ONE group of eight output channels of the chunk (its K half): a lane reads 16
+    // bytes of a row (ds_read_b128; the lane halves take channels 0-3 / 4-7 of the group: any
+    // assignment of K to the halves will do as long as both operands use the same) and feeds four
+    // matrix instructions per component and tile.  Eight lanes x 16 bytes cover the 32 banks once;
+    // the 8-byte reads of the first version met two per bank pair (csrc/fwd_min.hip: the fragment
+    // reads cost a fifth of a stage).
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
     auto compute = [&](int u_) {
         const unsigned char *st = smem + u_ * DM_STAGE;
+        const int ko = 32 * ks;
+        f32x4_ g[4][4];
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int kg = 2 * ks + gi;                 // group of 4 output channels (16 bytes of a row)
-            f32x2 g[4][4];
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int v = 0; v < 4; ++v)
+                g[u][v] = *(const f32x4_ *)(st + bb[u][v >> 1] + (v & 1) * (4 * DM_BARR) + ko);
+        // columns, then rows
+        f32x4_ cc[4][3], s[9];
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    g[u][v] = *(const f32x2 *)(st + bb[u][v >> 1] + (v & 1) * (4 * DM_BARR) + 16 * kg);
-            // columns, then rows
-            f32x2 cc[4][3], s[9];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                cc[u][0] = g[u][1] + g[u][2];
-                cc[u][1] = g[u][2] + g[u][3];
-                cc[u][2] = g[u][0] - g[u][2];
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                s[q] = cc[1][q] + cc[2][q];
-                s[3 + q] = cc[2][q] + cc[3][q];
-                s[6 + q] = cc[0][q] - cc[2][q];
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    const f32x2 a = *(const f32x2 *)(st + abase + (16 * c + 8 * t) * 64 + 16 * kg);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], s[c][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], s[c][1], acc[t], 0, 0, 0);
-                }
+        for (int u = 0; u < 4; ++u) {
+            cc[u][0] = g[u][1] + g[u][2];
+            cc[u][1] = g[u][2] + g[u][3];
+            cc[u][2] = g[u][0] - g[u][2];
         }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            s[q] = cc[1][q] + cc[2][q];
+            s[3 + q] = cc[2][q] + cc[3][q];
+            s[6 + q] = cc[0][q] - cc[2][q];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const f32x4_ a = *(const f32x4_ *)(st + abase + (16 * c + 8 * t) * 64 + ko);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], s[c][j], acc[t], 0, 0, 0);
+            }
     };
 
     if (item0 >= item1) return;
