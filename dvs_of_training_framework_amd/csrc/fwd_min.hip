@@ -304,6 +304,9 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
     // hand-written instruction hides from the hazard recogniser (without them: wrong sums):
     // 109 / 101 / 107 / 118 us per stage against 105 / 102 / 109 / 121, 2.518 against 2.526 ms per
     // step -- the K loop is not bound by its vector instructions.)
+    // (... and again with the 16-byte reads, which left the registers for it -- the next group's nine
+    // patch fragments fetched ahead of this group's 36 matrix instructions, 256 registers: 98 / 98 /
+    // 102 / 114 us per stage against 97 / 95 / 103 / 112.)
     // (Measured and not kept, batch 8: the next group's 18 fragment reads issued ahead of this
     // group's matrix instructions -- register double buffering, with and without
     // sched_group_barrier ordering: 105-136 / 108-164 us per stage against 101-119; the two
