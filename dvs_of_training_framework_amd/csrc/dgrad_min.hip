@@ -27,9 +27,12 @@
 // images as in fwd_min.hip (rows dealt to arrays by residue, arrays padded by
 // 16 bytes: no swizzle, the channel group is an immediate offset); the fine
 // patch is cut into even and odd columns because a fragment read walks it with
-// stride 2.  Epilogue: the two K halves meet in LDS, transposed to pixel-major;
-// 8 lanes store one pixel's 128 bytes into the member (x or skip) the channel
-// tile belongs to: + addend(s), x act'(actsrc) as the shared epilogue does.
+// stride 2.  Epilogue: the two K halves meet in LDS (a wave hands its partner the
+// tile it does not finish), each wave turns its tile to pixel-major through 4 KB
+// of its own; 8 lanes store one pixel's 128 bytes into the member (x or skip) the
+// channel tile belongs to: + addend(s), + a folded flow head's term, x act'(actsrc).
+// Finest stage (32 output channels = two chunks): the weights stay in LDS and a
+// workgroup walks the pixel blocks of its channel tile (IPW = 0 below).
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -112,7 +115,16 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
         const unsigned tot = gridDim.x, x = wg & 7u, q = tot >> 3, r = tot & 7u;
         wg = x * q + min(x, r) + (wg >> 3);
     }
-    const int item0 = (int)wg * IPW, item1 = item0 + IPW;       // (the launch makes IPW divide `total`)
+    // IPW = 0, RESIDENT weights (two chunks of K only: 32 output channels, the finest stage): a
+    // workgroup keeps ONE channel tile and walks pixel blocks r0, r0 + rows, ...; the weights of
+    // chunk 0 / 1 stay in stage 0 / 1 for all of them and only the patch is fetched per item --
+    // half of an item's LDS-DMA bytes (74 of 152 KB), which at 2.6 us of matrix work per item is
+    // what an item waits for.  The epilogue's exchange then lives in stage 1's PATCH area.
+    constexpr bool RES = IPW == 0;
+    const int rows = RES ? (int)gridDim.x / nct : 1;
+    const int item0 = RES ? ((int)wg / nct) * nct + (int)wg % nct : (int)wg * IPW;
+    const int istep = RES ? rows * nct : 1;
+    const int item1 = RES ? total : item0 + IPW;       // (the launch makes IPW divide `total`)
 
     const GSrc &GS = P.src[0];
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void *)P.W, 0, 0x7fffffff, 0x00020000);
@@ -161,6 +173,7 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
         }
     };
 
+    bool with_w = true;     // (resident mode: false once both stages hold their weights)
     auto issue = [&](int stage_idx, int ch) {
         unsigned char *st = smem + stage_idx * DM_STAGE;
         // (scalar offsets pinned to SGPRs here: as loop-carried values the compiler takes them
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
         for (int i = 0; i < DM_LPW; ++i) {
             const int p = wave + 8 * i;
             if (p < DM_AP) {
+                if (RES && !with_w) continue;
                 const int m = p / 9, pp = p - 9 * m;
                 __attribute__((address_space(3))) void *dst =
                     (__attribute__((address_space(3))) void *)(st + m * DM_AARR + pp * 1024);
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
     setup(item0);
     issue(0, 0);
 #pragma unroll
-    for (int item = item0; item < item1; ++item) {
+    for (int item = item0; item < item1; item += istep) {
         const int e_ci0 = ci0, e_b = b, e_oy = oy, e_ox = ox, e_blk = blk_;      // this item's (setup moves on below)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -262,8 +276,9 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (ch + 1 < nchunks) issue((ch + 1) & 1, ch + 1);
-            else if (item + 1 < item1) {    // the next item's first chunk
-                setup(item + 1);
+            else if (item + istep < item1) {    // the next item's first chunk
+                with_w = false;
+                setup(item + istep);
                 issue((ch + 1) & 1, 0);
             }
             compute(ch & 1);
@@ -271,7 +286,8 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
 
         // ---- epilogue: [wave][tile][pixel 32][ci 32] rows of 128 bytes, chunks XOR-swizzled by pixel & 7,
         // in the stage that was multiplied last (the other one is receiving the next item's chunk)
-        unsigned char *xch = smem + ((nchunks - 1) & 1) * DM_STAGE;
+        // (resident weights: in stage 1's patch area -- 41 KB, the exchange takes 32 + 2)
+        unsigned char *xch = RES ? smem + DM_STAGE + DM_BOFF : smem + ((nchunks - 1) & 1) * DM_STAGE;
         // this wave finishes channel tile t = ks of its pixel tile: which member, where in it
         const int cit = e_ci0 + 32 * ks;
         const int c_first = P.dst[0].C;
@@ -315,24 +331,43 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
             }
         }
         __builtin_amdgcn_s_barrier();       // every wave is done with the last chunk's stage
+        // (1) the K halves meet: a wave hands the tile it does NOT finish (t = 1 - ks) to its partner
+        // (pt, 1 - ks) in the matrix instruction's own register layout, 4 KB per wave ...
+        f32x16 mine = ks ? acc[1] : acc[0];
+        {
+            const f32x16 other = ks ? acc[0] : acc[1];
+            unsigned char *r1 = xch + wave * 4096;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            unsigned char *xt_ = xch + (wave * 2 + t) * 4096;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                *(f32x4 *)(xt_ + elrow * 128 + (((2 * g + elh) ^ (elrow & 7)) << 4)) = v;
-            }
+            for (int g = 0; g < 4; ++g)
+                *(f32x4 *)(r1 + (g * 64 + le) * 16) = f32x4{other[4 * g], other[4 * g + 1], other[4 * g + 2], other[4 * g + 3]};
         }
         __builtin_amdgcn_s_barrier();
+        {
+            const unsigned char *p1 = xch + (pt + 4 * (1 - ks)) * 4096;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o_ = *(const f32x4 *)(p1 + (g * 64 + le) * 16);
+                // (the K half 0 wave's value first, as the two-tile exchange summed them)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mine[4 * g + e] = ks ? o_[e] + mine[4 * g + e] : mine[4 * g + e] + o_[e];
+            }
+        }
+        __builtin_amdgcn_s_barrier();       // the partners have read: the regions are the waves' own again
+        // (2) ... and the wave turns its tile to pixel-major through its own 4 KB (rows of 128 bytes,
+        // chunks XOR-swizzled by pixel & 7): 8 lanes then hold one pixel's 32 channels
+        unsigned char *r2 = xch + wave * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {mine[4 * g], mine[4 * g + 1], mine[4 * g + 2], mine[4 * g + 3]};
+            *(f32x4 *)(r2 + elrow * 128 + (((2 * g + elh) ^ (elrow & 7)) << 4)) = v;
+        }
         f32x4 ha0 = {0.f, 0.f, 0.f, 0.f}, ha1 = ha0;
         float hs0 = 0.f, hs1 = 0.f;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int px = 8 * it + (le >> 3);
             const int xo = px * 128 + ((ecq ^ (px & 7)) << 4);
-            f32x4 v = *(const f32x4 *)(xch + (pt * 2 + ks) * 4096 + xo) +
-                      *(const f32x4 *)(xch + ((pt + 4) * 2 + ks) * 4096 + xo);
+            f32x4 v = *(const f32x4 *)(r2 + xo);
             if (D.addend) v += ead[it];
             if (D.addend2) v += ead2[it];
             if (D.head_w) v += eg0[it] * hw0 + eg1[it] * hw1;     // + W_h^T g_flow (dvsof_flow_head_bwd's data part)
@@ -361,8 +396,8 @@ __global__ __launch_bounds__(DM_NT) void dgrad_min_f32_kernel(const GConvParams 
                 hs0 += __shfl_xor(hs0, o_, 64);
                 hs1 += __shfl_xor(hs1, o_, 64);
             }
-            // [wave][2][32] + [wave][2] behind the exchange tiles of this stage (64 KiB of its 77)
-            float *red = (float *)(xch + 65536);
+            // [wave][2][32] + [wave][2] behind the exchange tiles (32 KiB)
+            float *red = (float *)(xch + 32768);
             if (le < 8) {
                 *(f32x4 *)(red + (wave * 2 + 0) * 32 + 4 * ecq) = ha0;
                 *(f32x4 *)(red + (wave * 2 + 1) * 32 + 4 * ecq) = ha1;
@@ -439,6 +474,20 @@ int dgrad_min_launch(const GConvParams &P, hipStream_t st)
     const int nchunks = P.Cin_tot / 16;
     int ipw = ipw_env == 2 ? 2 : 1;
     if ((nchunks & 1) || (total & 1)) ipw = 1;
+    // resident weights (two chunks of K): 256 workgroups (whole channel-tile rows of them), >= 2 items each
+    static const bool no_res = getenv("DVSOF_DGRAD_MIN_RESIDENT") && atoi(getenv("DVSOF_DGRAD_MIN_RESIDENT")) == 0;
+    const int nct = P.N / 64;
+    if (!no_res && !ipw_env && nchunks == 2 && 256 % nct == 0 && total >= 2 * 256) {
+        static bool attr0 = false;
+        if (!attr0) {
+            DVSOF_HIP_TRY(hipFuncSetAttribute((const void *)dgrad_min_f32_kernel<0>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, DM_LDS));
+            attr0 = true;
+        }
+        hipLaunchKernelGGL(dgrad_min_f32_kernel<0>, dim3(256), dim3(DM_NT), DM_LDS, st, P, (int)total);
+        DVSOF_LAUNCH_CHECK();
+        return DVSOF_OK;
+    }
     if (ipw == 2)
         hipLaunchKernelGGL(dgrad_min_f32_kernel<2>, dim3((unsigned)(total / 2)), dim3(DM_NT), DM_LDS, st, P, (int)total);
     else
