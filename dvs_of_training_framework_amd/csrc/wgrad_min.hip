@@ -167,15 +167,21 @@ __global__ __launch_bounds__(WM_NT) void wgrad_min_f32_kernel(const WGradParams 
     auto compute = [&](int u) {
         const unsigned char *st = smem + u * WM_STAGE;
         float g[2][4], x[2][9];
+#ifndef WM_PROBE
+#define WM_PROBE 0      // timing probes (variant builds; results wrong): 1 no DMA behind the ring's first fill,
+#endif                  // 2 one gradient and one input fragment read per K step instead of 13, 4 no stage barrier.
+                        // Per stage with its slab reduce, us: 117 112 107 107 | 1: 110 101 97 97 | 2: 103 95 93 94 |
+                        // 4: 110 103 99 99 | 7: 92 83 83 83: reads 13 %, DMA 8 %, barrier 7 % -- no single cost
         auto fetch = [&](int buf, int j) {
 #pragma unroll
-            for (int ph = 0; ph < 4; ++ph) g[buf][ph] = *(const float *)(st + gaddr + (ph * 32 + 2 * j) * 128);
+            for (int ph = 0; ph < 4; ++ph)
+                g[buf][ph] = *(const float *)(st + gaddr + (((WM_PROBE & 2) ? 0 : ph) * 32 + 2 * j) * 128);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    x[buf][3 * r + c] =
-                        *(const float *)(st + ((c & 1) ? xodd : xeven) + (r * 18 + c + 2 * j) * WM_PXB);
+                    x[buf][3 * r + c] = *(const float *)(st + (((WM_PROBE & 2) ? 0 : (c & 1)) ? xodd : xeven) +
+                                                         (((WM_PROBE & 2) ? 0 : r * 18 + c) + 2 * j) * WM_PXB);
         };
         fetch(0, 0);
 #pragma unroll
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(WM_NT) void wgrad_min_f32_kernel(const WGradParams 
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                __builtin_amdgcn_s_barrier();
-                if (st + WM_NS - 1 < nsteps) issue((u + WM_NS - 1) % WM_NS);
+                if (!(WM_PROBE & 4) || st == 0) __builtin_amdgcn_s_barrier();
+                if (st + WM_NS - 1 < nsteps && (!(WM_PROBE & 1) || st == 0)) issue((u + WM_NS - 1) % WM_NS);
                 compute(u);
             }
         }
