@@ -298,6 +298,11 @@ __global__ __launch_bounds__(FM_NT) void fwd_min_f32_kernel(const GConvParams P)
         compute(ch & 1);
     }
 
+    // (Measured and not kept: NO barrier in the K loop -- per stage an arrival and a release counter
+    // in LDS (a wave signals that its DMA pieces landed / that it has read its last fragment, spins
+    // -- bounded -- until all eight have; the next chunk's DMA issued between a wave's two groups):
+    // correct, and 113 / 95 / 101 / 113 us per stage against 93 / 93 / 98 / 110 -- the polls cost
+    // more than the barrier's bubble.)
     // (Measured and not kept: the twelve subtractions pinned to v_pk_add_f32 by inline asm -- the
     // compiler splits most of them into scalar pairs, 86 v_add_f32 per unrolled chunk -- with the
     // two wait states a matrix instruction needs behind a vector write of its operand, which a
